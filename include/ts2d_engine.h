@@ -1,0 +1,112 @@
+/* ts2d_engine.h - C-ABI of the MI355X-native 2-D U-Net inference engine (libts2d_engine.so).
+ *
+ * Drop-in boundary.  The reference has no FFI: its seam is the duck-typed predictor object
+ * consumed by `_run_predict` (reference ts2d/core/inference/prediction_worker.py:177-242).  These entry points are
+ * what a ctypes/cffi binding placed at that seam binds; each cites the reference interface it replaces.
+ * Plain pointers and sizes only - no torch / HIP types in any signature (streams travel as void*).
+ *
+ * Error convention (replaces Python exceptions, reference prediction_worker.py:183-242 / nnu.py:217-219): every
+ * function returns 0 on success or a negative ts2d_status; ts2d_last_error() returns a thread-local message that
+ * the Python layer converts to RuntimeError.  The library never aborts the process.
+ *
+ * Threading: one caller thread per engine handle (reference: one worker process per sub-model, one task at a
+ * time, prediction_worker.py:127-165).  Handles are independent (different sub-models / GPUs).
+ */
+#ifndef TS2D_ENGINE_H
+#define TS2D_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TS2D_MAX_STAGES 16
+
+typedef enum {
+    TS2D_OK = 0,
+    TS2D_ERR_INVALID = -1,     /* bad argument / unsupported architecture or shape */
+    TS2D_ERR_HIP = -2,         /* a HIP runtime call or kernel launch failed */
+    TS2D_ERR_NOMEM = -3,       /* device or host allocation failed */
+    TS2D_ERR_STATE = -4        /* engine not initialised (e.g. weights not yet broadcast) */
+} ts2d_status;
+
+/* Architecture descriptor = the `arch_kwargs` of nnU-Net's PlainConvUNet that
+ * `nnUNetPredictor.initialize_from_trained_model_folder` (reference call site ts2d/core/inference/nnu.py:165) reads
+ * from plans.json.  Supported subset: Conv2d 3x3, stride 1 first stage / 2 afterwards, InstanceNorm2d(affine),
+ * LeakyReLU, ConvTranspose2d 2x2 upsampling, 1x1 head.  features[] must be multiples of 32. */
+typedef struct {
+    int32_t input_channels;                 /* C: len(dataset_json['channel_names']) (prediction_worker.py:78) */
+    int32_t num_classes;                    /* K: number of segmentation heads (multilabel: one per label) */
+    int32_t n_stages;
+    int32_t features[TS2D_MAX_STAGES];
+    int32_t n_conv_enc[TS2D_MAX_STAGES];
+    int32_t n_conv_dec[TS2D_MAX_STAGES];    /* n_stages-1 entries, bottom-up (decoder.stages.{j}) */
+    float norm_eps;                         /* InstanceNorm2d eps (1e-5) */
+    float leaky_slope;                      /* LeakyReLU negative_slope (0.01) */
+} ts2d_arch_desc;
+
+typedef struct ts2d_engine ts2d_engine;
+
+/* Create an engine on HIP device `device`.
+ * Replaces: nnUNetPredictor(...).initialize_from_trained_model_folder(model, folds, checkpoint) for ONE fold
+ * (reference nnu.py:164-165): network construction + load_state_dict.
+ * `weights`: host pointer to the fp32 blob = every parameter tensor in PyTorch layout, concatenated in program order
+ * (encoder.stages.{s}.0.convs.{i}.{conv.weight,conv.bias,norm.weight,norm.bias} ..., decoder.transpconvs.{j}.{weight,
+ * bias}, decoder.stages.{j}.convs.{i}..., decoder.seg_layers.{n-2}.{weight,bias}); n_floats must match exactly.
+ * `weights` may be NULL: the engine is then created with uninitialised device weights that MUST be filled by a
+ * broadcast into ts2d_engine_weight_buffer() followed by ts2d_engine_weights_ready() (multi-GPU replicas). */
+int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t n_floats, int device,
+                       ts2d_engine** out);
+
+/* Replace the weights of an existing engine (fold switch: `network.load_state_dict(params)` in
+ * predict_logits_from_preprocessed_data, reference call site prediction_worker.py:209). */
+int ts2d_engine_load_weights(ts2d_engine* e, const float* weights, size_t n_floats);
+
+/* Weight-broadcast hook: device pointer + byte size of the packed weight arena.  Rank 0 creates with
+ * weights, the other ranks with NULL; all ranks broadcast this buffer (RCCL, root 0), then call
+ * ts2d_engine_weights_ready(). */
+int ts2d_engine_weight_buffer(ts2d_engine* e, void** dev_ptr, size_t* n_bytes);
+int ts2d_engine_weights_ready(ts2d_engine* e);
+
+/* One batched forward pass = `network(x)` (reference: nnUNetPredictor.network.__call__ inside
+ * _internal_maybe_mirror_and_predict; the reference always uses B = 1).
+ *   input        [B, C, H, W] fp32 NCHW (what `data[None]` is in the reference), host or device memory
+ *   logits       [B, K, H, W] fp32 NCHW or NULL
+ *   mask_packed  [B, K, H, W/32] uint32 or NULL: bit (x & 31) of word x>>5 = (sigmoid(float(logit)) > 0.5), the
+ *                multilabel export predicate (reference export_prediction_from_logits, prediction_worker.py:215-221)
+ *   H, W         multiples of 2^(n_stages-1); W multiple of 32 when mask_packed != NULL
+ *   on_device    nonzero: input/logits/mask_packed are device pointers; zero: host pointers (staged by the engine)
+ *   stream       hipStream_t as void* (NULL = the engine's own stream).  The call is asynchronous when on_device
+ *                != 0 (caller synchronises the stream) and synchronous otherwise. */
+int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W, float* logits,
+                        uint32_t* mask_packed, int on_device, void* stream);
+
+/* Pre-allocate the activation workspace for (B, H, W) (reference warm-up contract: a zero patch is pushed through
+ * the predictor once at start-up, prediction_worker.py:74-96,136-138). */
+int ts2d_engine_reserve(ts2d_engine* e, int B, int H, int W);
+
+/* Per-op device timing (HIP events on the launch stream).  enable != 0 brackets every kernel of subsequent forwards
+ * with events; ts2d_engine_op_times returns for the LAST forward the elapsed ms per op (n_ops entries, program
+ * order; see ts2d_engine_op_name) - synchronises the stream. */
+int ts2d_engine_set_profiling(ts2d_engine* e, int enable);
+int ts2d_engine_num_ops(ts2d_engine* e);
+const char* ts2d_engine_op_name(ts2d_engine* e, int op);
+int ts2d_engine_op_times(ts2d_engine* e, float* ms, int n_ops);
+
+/* Bytes of device memory currently held (weights + workspace). */
+size_t ts2d_engine_device_bytes(ts2d_engine* e);
+
+int ts2d_engine_destroy(ts2d_engine* e);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* ts2d_last_error(void);
+
+/* ABI version of this header (bumped on any signature change). */
+int ts2d_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TS2D_ENGINE_H */

@@ -1,0 +1,528 @@
+// libts2d_engine.so - host side of the MI355X-native 2-D U-Net engine + the C-ABI of include/ts2d_engine.h.
+// Replaces the network-forward part of nnUNetPredictor (reference seam: ts2d/core/inference/prediction_worker.py:209,
+// network built at ts2d/core/inference/nnu.py:164-165).  gfx950 only; no CPU fallback exists in this library.
+#include "../../include/ts2d_engine.h"
+#include "kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ts2d;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return fail(_e == hipErrorOutOfMemory ? TS2D_ERR_NOMEM : TS2D_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(_e), __FILE__, __LINE__);                                \
+    } while (0)
+
+enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_HEAD = 2 };
+
+struct Tensor {            // an activation tensor of the program (NHWC fp32)
+    std::string name;
+    int C = 0, level = 0;
+    bool normed = false;   // raw conv output that carries InstanceNorm scale/shift
+    float* data = nullptr; float* scale = nullptr; float* shift = nullptr;
+};
+
+struct Op {
+    OpType type; std::string name;
+    int src, skip, dst;           // tensor indices (skip = -1 if none)
+    int cin, cin_skip, cout, stride, level;
+    int ck;                       // Cin chunk of the packed weight layout
+    size_t blob_w, blob_b, blob_g, blob_be;     // offsets (floats) into the PyTorch-layout blob
+    size_t dev_w, dev_b, dev_g, dev_be;         // offsets (floats) into the device weight arena
+    size_t dev_w_floats;
+};
+
+struct Launch { std::string name; hipEvent_t e0 = nullptr, e1 = nullptr; };
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+}  // namespace
+
+struct ts2d_engine {
+    ts2d_arch_desc arch{};
+    int device = 0;
+    int cin_pad = 8;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    size_t blob_floats = 0;
+    float* d_weights = nullptr; size_t weight_floats = 0;
+    bool weights_ready = false;
+    // workspace
+    char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
+    float* d_part = nullptr;
+    float* d_in_stage = nullptr; float* d_logit_stage = nullptr; uint32_t* d_mask_stage = nullptr;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    std::vector<Launch> launches; size_t n_launched = 0;
+};
+
+namespace {
+
+int tensor_index(ts2d_engine* e, const std::string& name) {
+    for (size_t i = 0; i < e->tensors.size(); ++i) if (e->tensors[i].name == name) return (int)i;
+    return -1;
+}
+
+int add_tensor(ts2d_engine* e, const std::string& name, int C, int level, bool normed) {
+    Tensor t; t.name = name; t.C = C; t.level = level; t.normed = normed;
+    e->tensors.push_back(t);
+    return (int)e->tensors.size() - 1;
+}
+
+// Mirror of UNetArch.program() (totalsegmentator2d_amd/arch.py): PlainConvUNet forward order.
+int build_program(ts2d_engine* e) {
+    const ts2d_arch_desc& a = e->arch;
+    if (a.n_stages < 2 || a.n_stages > TS2D_MAX_STAGES) return fail(TS2D_ERR_INVALID, "n_stages %d out of range [2,%d]", a.n_stages, TS2D_MAX_STAGES);
+    if (a.input_channels < 1 || a.num_classes < 1) return fail(TS2D_ERR_INVALID, "input_channels / num_classes must be positive");
+    if (a.num_classes > 256) return fail(TS2D_ERR_INVALID, "num_classes %d > 256 is not supported", a.num_classes);
+    for (int s = 0; s < a.n_stages; ++s) {
+        if (a.features[s] < 32 || a.features[s] % 32) return fail(TS2D_ERR_INVALID, "features[%d] = %d must be a positive multiple of 32", s, a.features[s]);
+        if (a.n_conv_enc[s] < 1) return fail(TS2D_ERR_INVALID, "n_conv_enc[%d] must be >= 1", s);
+        if (s < a.n_stages - 1 && a.n_conv_dec[s] < 1) return fail(TS2D_ERR_INVALID, "n_conv_dec[%d] must be >= 1", s);
+    }
+    if (a.features[0] != 32 && a.features[0] != 64) return fail(TS2D_ERR_INVALID, "features[0] = %d: the head kernel supports 32 or 64", a.features[0]);
+    e->cin_pad = (a.input_channels + 7) / 8 * 8;
+    size_t bo = 0;
+    int cur = add_tensor(e, "input", e->cin_pad, 0, false), cin = a.input_channels;
+    std::vector<int> skips(a.n_stages);
+    char nm[64];
+    for (int s = 0; s < a.n_stages; ++s) {
+        const int f = a.features[s];
+        for (int i = 0; i < a.n_conv_enc[s]; ++i) {
+            snprintf(nm, sizeof(nm), "enc%d.c%d", s, i);
+            Op op{}; op.type = OP_CONV; op.name = nm; op.src = cur; op.skip = -1;
+            op.cin = cin; op.cin_skip = 0; op.cout = f; op.stride = (i == 0 && s > 0) ? 2 : 1; op.level = s;
+            op.dst = add_tensor(e, nm, f, s, true);
+            op.blob_w = bo; bo += (size_t)f * cin * 9; op.blob_b = bo; bo += f; op.blob_g = bo; bo += f; op.blob_be = bo; bo += f;
+            e->ops.push_back(op);
+            cur = op.dst; cin = f;
+        }
+        skips[s] = cur;
+    }
+    for (int j = 0; j < a.n_stages - 1; ++j) {
+        const int lvl = a.n_stages - 2 - j, f = a.features[lvl];
+        snprintf(nm, sizeof(nm), "dec%d.up", lvl);
+        Op up{}; up.type = OP_CONVT; up.name = nm; up.src = cur; up.skip = -1; up.cin = cin; up.cin_skip = 0; up.cout = f;
+        up.stride = 2; up.level = lvl; up.dst = add_tensor(e, nm, f, lvl, false);
+        up.blob_w = bo; bo += (size_t)cin * f * 4; up.blob_b = bo; bo += f;
+        e->ops.push_back(up);
+        cur = up.dst;
+        for (int i = 0; i < a.n_conv_dec[j]; ++i) {
+            snprintf(nm, sizeof(nm), "dec%d.c%d", lvl, i);
+            Op op{}; op.type = OP_CONV; op.name = nm; op.src = cur; op.skip = (i == 0) ? skips[lvl] : -1;
+            op.cin = f; op.cin_skip = (i == 0) ? f : 0; op.cout = f; op.stride = 1; op.level = lvl;
+            op.dst = add_tensor(e, nm, f, lvl, true);
+            const int ct = op.cin + op.cin_skip;
+            op.blob_w = bo; bo += (size_t)f * ct * 9; op.blob_b = bo; bo += f; op.blob_g = bo; bo += f; op.blob_be = bo; bo += f;
+            e->ops.push_back(op);
+            cur = op.dst;
+        }
+        cin = f;
+    }
+    {
+        Op hd{}; hd.type = OP_HEAD; hd.name = "head"; hd.src = cur; hd.skip = -1; hd.cin = cin; hd.cin_skip = 0;
+        hd.cout = a.num_classes; hd.stride = 1; hd.level = 0; hd.dst = -1;
+        hd.blob_w = bo; bo += (size_t)a.num_classes * cin; hd.blob_b = bo; bo += a.num_classes;
+        e->ops.push_back(hd);
+    }
+    e->blob_floats = bo;
+    // device weight arena layout
+    size_t wo = 0;
+    for (Op& op : e->ops) {
+        const int ct = op.cin + op.cin_skip;
+        if (op.type == OP_CONV) {
+            const int ctp = (op.src == 0) ? e->cin_pad : ct;             // first conv reads the zero-padded input
+            op.ck = (op.stride == 2 || ctp % 16) ? 8 : 16;
+            op.dev_w_floats = (size_t)ctp * 9 * op.cout;
+        } else if (op.type == OP_CONVT) {
+            op.ck = 16;
+            op.dev_w_floats = (size_t)ct * 4 * op.cout;
+        } else {
+            op.ck = 0;
+            op.dev_w_floats = (size_t)ct * op.cout;
+        }
+        op.dev_w = wo; wo = align_up(wo + op.dev_w_floats, 64);
+        op.dev_b = wo; wo = align_up(wo + op.cout, 64);
+        if (op.type == OP_CONV) { op.dev_g = wo; wo = align_up(wo + op.cout, 64); op.dev_be = wo; wo = align_up(wo + op.cout, 64); }
+    }
+    e->weight_floats = wo;
+    return TS2D_OK;
+}
+
+// PyTorch-layout blob -> packed device layouts (host staging buffer `out`, weight_floats long).
+void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
+    memset(out, 0, e->weight_floats * sizeof(float));
+    for (const Op& op : e->ops) {
+        const int ct = op.cin + op.cin_skip, co_n = op.cout;
+        if (op.type == OP_CONV) {           // W[co][ci][ky][kx] -> [chunk][tap][kk][co][8]
+            const int ck = op.ck, kkn = ck / 8;
+            const float* w = blob + op.blob_w;
+            float* d = out + op.dev_w;
+            for (int co = 0; co < co_n; ++co)
+                for (int ci = 0; ci < ct; ++ci) {
+                    const int chunk = ci / ck, cc = ci % ck, kk = cc / 8, el = cc % 8;
+                    for (int tap = 0; tap < 9; ++tap)
+                        d[((((size_t)chunk * 9 + tap) * kkn + kk) * co_n + co) * 8 + el] = w[((size_t)co * ct + ci) * 9 + tap];
+                }
+            memcpy(out + op.dev_g, blob + op.blob_g, co_n * sizeof(float));
+            memcpy(out + op.dev_be, blob + op.blob_be, co_n * sizeof(float));
+        } else if (op.type == OP_CONVT) {   // W[ci][co][a][b] -> [chunk][kk][(a*2+b)*Cout + co][8]
+            const int ck = op.ck, kkn = ck / 8, N = 4 * co_n;
+            const float* w = blob + op.blob_w;
+            float* d = out + op.dev_w;
+            for (int ci = 0; ci < ct; ++ci) {
+                const int chunk = ci / ck, cc = ci % ck, kk = cc / 8, el = cc % 8;
+                for (int co = 0; co < co_n; ++co)
+                    for (int ab = 0; ab < 4; ++ab)
+                        d[(((size_t)chunk * kkn + kk) * N + ab * co_n + co) * 8 + el] = w[((size_t)ci * co_n + co) * 4 + ab];
+            }
+        } else {                            // head W[k][c] as is
+            memcpy(out + op.dev_w, blob + op.blob_w, (size_t)ct * co_n * sizeof(float));
+        }
+        memcpy(out + op.dev_b, blob + op.blob_b, co_n * sizeof(float));
+    }
+}
+
+int upload_weights(ts2d_engine* e, const float* blob, size_t n_floats) {
+    if (n_floats != e->blob_floats)
+        return fail(TS2D_ERR_INVALID, "weight blob has %zu floats, architecture needs %zu", n_floats, e->blob_floats);
+    std::vector<float> staging;
+    try { staging.resize(e->weight_floats); } catch (...) { return fail(TS2D_ERR_NOMEM, "host staging allocation failed"); }
+    pack_weights(e, blob, staging.data());
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(e->d_weights, staging.data(), e->weight_floats * sizeof(float), hipMemcpyHostToDevice));
+    e->weights_ready = true;
+    return TS2D_OK;
+}
+
+struct TileGeom { int lgTH, lgTW, lgNIMG, tiles_x, tiles_y, n_mtiles, PH, PW; };
+
+TileGeom tile_geom(int B, int Ht, int Wt, int stride, int taps) {
+    TileGeom g{};
+    const int TW = std::min(32, pow2ceil(Wt));
+    const int TH = std::min(pow2ceil(Ht), kBM / TW);
+    int NIMG = std::min(16, kBM / (TH * TW));
+    g.lgTH = ilog2(TH); g.lgTW = ilog2(TW); g.lgNIMG = ilog2(NIMG);
+    if (NIMG > 1) { g.tiles_x = 1; g.tiles_y = 1; }
+    else { g.tiles_x = (Wt + TW - 1) / TW; g.tiles_y = (Ht + TH - 1) / TH; }
+    const int groups = (B + NIMG - 1) / NIMG;
+    g.n_mtiles = groups * g.tiles_x * g.tiles_y;
+    const int halo = (taps == 9) ? 3 : 1;
+    g.PH = (TH - 1) * stride + halo; g.PW = (TW - 1) * stride + halo;
+    return g;
+}
+
+template <int TAPS, int STRIDE, int CK, int BN, int EPI>
+hipError_t launch_conv_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv_mfma_f32<TAPS, STRIDE, CK, BN, EPI>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), smem, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(int taps, int stride, int ck, int bn, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    if (taps == 9 && stride == 1 && ck == 16 && bn == 32) return launch_conv_inst<9, 1, 16, 32, 0>(a, grid, smem, st);
+    if (taps == 9 && stride == 1 && ck == 16 && bn == 64) return launch_conv_inst<9, 1, 16, 64, 0>(a, grid, smem, st);
+    if (taps == 9 && stride == 1 && ck == 8 && bn == 32) return launch_conv_inst<9, 1, 8, 32, 0>(a, grid, smem, st);
+    if (taps == 9 && stride == 1 && ck == 8 && bn == 64) return launch_conv_inst<9, 1, 8, 64, 0>(a, grid, smem, st);
+    if (taps == 9 && stride == 2 && ck == 8 && bn == 32) return launch_conv_inst<9, 2, 8, 32, 0>(a, grid, smem, st);
+    if (taps == 9 && stride == 2 && ck == 8 && bn == 64) return launch_conv_inst<9, 2, 8, 64, 0>(a, grid, smem, st);
+    if (taps == 1 && stride == 1 && ck == 16 && bn == 32) return launch_conv_inst<1, 1, 16, 32, 1>(a, grid, smem, st);
+    if (taps == 1 && stride == 1 && ck == 16 && bn == 64) return launch_conv_inst<1, 1, 16, 64, 1>(a, grid, smem, st);
+    return hipErrorInvalidConfiguration;
+}
+
+size_t part_floats_needed(const ts2d_engine* e, int B, int H, int W) {
+    size_t mx = 0;
+    for (const Op& op : e->ops) {
+        if (op.type != OP_CONV) continue;
+        const int Ht = H >> op.level, Wt = W >> op.level;
+        TileGeom g = tile_geom(B, Ht, Wt, op.stride, 9);
+        if (g.lgNIMG == 0) mx = std::max(mx, (size_t)B * g.tiles_x * g.tiles_y * op.cout * 2);
+    }
+    return mx;
+}
+
+int ensure_workspace(ts2d_engine* e, int B, int H, int W) {
+    if (e->d_ws && e->wsB >= B && e->wsH == H && e->wsW == W) return TS2D_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->d_ws) { HIP_TRY(hipStreamSynchronize(e->stream)); HIP_TRY(hipFree(e->d_ws)); e->d_ws = nullptr; e->ws_bytes = 0; }
+    const int K = e->arch.num_classes;
+    size_t off = 0;
+    std::vector<size_t> o_data(e->tensors.size()), o_sc(e->tensors.size()), o_sh(e->tensors.size());
+    for (size_t i = 0; i < e->tensors.size(); ++i) {
+        const Tensor& t = e->tensors[i];
+        const size_t px = (size_t)B * (H >> t.level) * (W >> t.level);
+        o_data[i] = off; off = align_up(off + px * t.C * sizeof(float), 256);
+        if (t.normed) {
+            o_sc[i] = off; off = align_up(off + (size_t)B * t.C * sizeof(float), 256);
+            o_sh[i] = off; off = align_up(off + (size_t)B * t.C * sizeof(float), 256);
+        }
+    }
+    const size_t o_part = off; off = align_up(off + part_floats_needed(e, B, H, W) * sizeof(float) + 256, 256);
+    const size_t o_in = off; off = align_up(off + (size_t)B * e->arch.input_channels * H * W * sizeof(float), 256);
+    const size_t o_lg = off; off = align_up(off + (size_t)B * K * H * W * sizeof(float), 256);
+    const size_t o_mk = off; off = align_up(off + (size_t)B * K * H * ((W + 31) / 32) * sizeof(uint32_t), 256);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_ws), off));
+    e->ws_bytes = off; e->wsB = B; e->wsH = H; e->wsW = W;
+    for (size_t i = 0; i < e->tensors.size(); ++i) {
+        Tensor& t = e->tensors[i];
+        t.data = reinterpret_cast<float*>(e->d_ws + o_data[i]);
+        t.scale = t.normed ? reinterpret_cast<float*>(e->d_ws + o_sc[i]) : nullptr;
+        t.shift = t.normed ? reinterpret_cast<float*>(e->d_ws + o_sh[i]) : nullptr;
+    }
+    e->d_part = reinterpret_cast<float*>(e->d_ws + o_part);
+    e->d_in_stage = reinterpret_cast<float*>(e->d_ws + o_in);
+    e->d_logit_stage = reinterpret_cast<float*>(e->d_ws + o_lg);
+    e->d_mask_stage = reinterpret_cast<uint32_t*>(e->d_ws + o_mk);
+    return TS2D_OK;
+}
+
+int prof_begin(ts2d_engine* e, const std::string& name, hipStream_t st) {
+    if (!e->profiling) return TS2D_OK;
+    if (e->n_launched >= e->launches.size()) {
+        Launch l; l.name = name;
+        HIP_TRY(hipEventCreate(&l.e0)); HIP_TRY(hipEventCreate(&l.e1));
+        e->launches.push_back(l);
+    }
+    e->launches[e->n_launched].name = name;
+    HIP_TRY(hipEventRecord(e->launches[e->n_launched].e0, st));
+    return TS2D_OK;
+}
+int prof_end(ts2d_engine* e, hipStream_t st) {
+    if (!e->profiling) return TS2D_OK;
+    HIP_TRY(hipEventRecord(e->launches[e->n_launched].e1, st));
+    e->n_launched++;
+    return TS2D_OK;
+}
+
+#define TRY(expr) do { int _rc = (expr); if (_rc != TS2D_OK) return _rc; } while (0)
+
+int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st) {
+    const ts2d_arch_desc& a = e->arch;
+    e->n_launched = 0;
+    {   // boundary layout change NCHW -> NHWC (channels zero-padded to 8)
+        const long long total = (long long)B * H * W;
+        TRY(prof_begin(e, "input.nhwc", st));
+        hipLaunchKernelGGL(nchw_to_nhwc_pad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           d_in, a.input_channels, H * W, total, e->cin_pad, e->tensors[0].data);
+        HIP_TRY(hipGetLastError());
+        TRY(prof_end(e, st));
+    }
+    for (const Op& op : e->ops) {
+        const Tensor& src = e->tensors[op.src];
+        const float* wts = e->d_weights;
+        if (op.type == OP_CONV || op.type == OP_CONVT) {
+            const bool conv = op.type == OP_CONV;
+            Tensor& dst = e->tensors[op.dst];
+            const int Hin = H >> src.level, Win = W >> src.level;
+            const int Ht = conv ? (H >> op.level) : Hin, Wt = conv ? (W >> op.level) : Win;
+            const int taps = conv ? 9 : 1, stride = conv ? op.stride : 1;
+            const TileGeom g = tile_geom(B, Ht, Wt, stride, taps);
+            ConvArgs ca{};
+            ca.src0 = src.data; ca.sc0 = src.scale; ca.sh0 = src.shift; ca.C0 = src.C;
+            if (op.skip >= 0) { const Tensor& sk = e->tensors[op.skip]; ca.src1 = sk.data; ca.sc1 = sk.scale; ca.sh1 = sk.shift; ca.C1 = sk.C; }
+            ca.wp = wts + op.dev_w; ca.bias = wts + op.dev_b; ca.dst = dst.data;
+            const bool fused = conv && g.lgNIMG == 0;
+            ca.part = fused ? e->d_part : nullptr;
+            ca.B = B; ca.Hin = Hin; ca.Win = Win; ca.Ht = Ht; ca.Wt = Wt;
+            ca.N = conv ? op.cout : 4 * op.cout; ca.Cout = op.cout;
+            ca.lgTH = g.lgTH; ca.lgTW = g.lgTW; ca.lgNIMG = g.lgNIMG; ca.tiles_x = g.tiles_x; ca.tiles_y = g.tiles_y;
+            const int bn = (ca.N % 64 == 0 && op.cout % 64 == 0) ? 64 : 32;
+            ca.n_mtiles = g.n_mtiles; ca.n_ctiles = ca.N / bn; ca.PH = g.PH; ca.PW = g.PW; ca.slope = a.leaky_slope;
+            const int P = (g.PH * g.PW) << g.lgNIMG;
+            const size_t smem = std::max((size_t)(((P * (op.ck + 4) + 3) & ~3) + taps * (op.ck / 8) * bn * 8) * sizeof(float),
+                                         (size_t)4 * bn * 2 * sizeof(float));
+            if (smem > 160 * 1024) return fail(TS2D_ERR_INVALID, "op %s: LDS tile of %zu bytes exceeds 160 KiB", op.name.c_str(), smem);
+            const int grid = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
+            TRY(prof_begin(e, op.name, st));
+            hipError_t le = launch_conv(taps, stride, op.ck, bn, ca, grid, smem, st);
+            if (le != hipSuccess) return fail(TS2D_ERR_HIP, "launch of %s failed: %s", op.name.c_str(), hipGetErrorString(le));
+            TRY(prof_end(e, st));
+            if (conv) {
+                const int HW = Ht * Wt;
+                TRY(prof_begin(e, op.name + ".stats", st));
+                if (fused) {
+                    const int n = B * op.cout;
+                    hipLaunchKernelGGL(finalize_stats, dim3((n + 63) / 64), dim3(64), 0, st, e->d_part, g.tiles_x * g.tiles_y,
+                                       op.cout, B, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+                } else {
+                    hipLaunchKernelGGL(stats_direct, dim3(B, op.cout / 32), dim3(256), 0, st, dst.data, op.cout, HW,
+                                       wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+                }
+                HIP_TRY(hipGetLastError());
+                TRY(prof_end(e, st));
+            }
+        } else {
+            HeadArgs ha{};
+            ha.src = src.data; ha.sc = src.scale; ha.sh = src.shift; ha.w = wts + op.dev_w; ha.bias = wts + op.dev_b;
+            ha.logits = d_logits; ha.mask = d_mask; ha.C = src.C; ha.K = op.cout; ha.HW = H * W;
+            ha.total = (long long)B * H * W; ha.slope = a.leaky_slope;
+            const unsigned grid = (unsigned)((ha.total + 255) / 256);
+            const size_t smem = ((size_t)256 * (src.C + 1) + (size_t)op.cout * src.C + op.cout) * sizeof(float);
+            TRY(prof_begin(e, op.name, st));
+            if (src.C == 32) {
+                static bool set32 = false;
+                if (!set32) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set32 = true; }
+                hipLaunchKernelGGL(head_1x1<32>, dim3(grid), dim3(256), smem, st, ha);
+            } else {
+                static bool set64 = false;
+                if (!set64) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set64 = true; }
+                hipLaunchKernelGGL(head_1x1<64>, dim3(grid), dim3(256), smem, st, ha);
+            }
+            HIP_TRY(hipGetLastError());
+            TRY(prof_end(e, st));
+        }
+    }
+    return TS2D_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------- C-ABI
+extern "C" {
+
+int ts2d_abi_version(void) { return 1; }
+
+const char* ts2d_last_error(void) { return g_err.c_str(); }
+
+int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t n_floats, int device, ts2d_engine** out) {
+    if (!arch || !out) return fail(TS2D_ERR_INVALID, "ts2d_engine_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(TS2D_ERR_INVALID, "device %d out of range (%d HIP devices visible)", device, ndev);
+    ts2d_engine* e = new (std::nothrow) ts2d_engine();
+    if (!e) return fail(TS2D_ERR_NOMEM, "host allocation failed");
+    e->arch = *arch; e->device = device;
+    int rc = build_program(e);
+    if (rc != TS2D_OK) { delete e; return rc; }
+    hipError_t he = hipSetDevice(device);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&e->d_weights), e->weight_floats * sizeof(float));
+    if (he != hipSuccess) {
+        rc = fail(he == hipErrorOutOfMemory ? TS2D_ERR_NOMEM : TS2D_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he));
+        ts2d_engine_destroy(e);
+        return rc;
+    }
+    if (weights) {
+        rc = upload_weights(e, weights, n_floats);
+        if (rc != TS2D_OK) { ts2d_engine_destroy(e); return rc; }
+    }
+    *out = e;
+    return TS2D_OK;
+}
+
+int ts2d_engine_load_weights(ts2d_engine* e, const float* weights, size_t n_floats) {
+    if (!e || !weights) return fail(TS2D_ERR_INVALID, "ts2d_engine_load_weights: null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return upload_weights(e, weights, n_floats);
+}
+
+int ts2d_engine_weight_buffer(ts2d_engine* e, void** dev_ptr, size_t* n_bytes) {
+    if (!e || !dev_ptr || !n_bytes) return fail(TS2D_ERR_INVALID, "ts2d_engine_weight_buffer: null argument");
+    *dev_ptr = e->d_weights; *n_bytes = e->weight_floats * sizeof(float);
+    return TS2D_OK;
+}
+
+int ts2d_engine_weights_ready(ts2d_engine* e) {
+    if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_weights_ready: null engine");
+    e->weights_ready = true;
+    return TS2D_OK;
+}
+
+int ts2d_engine_reserve(ts2d_engine* e, int B, int H, int W) {
+    if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_reserve: null engine");
+    const int div = 1 << (e->arch.n_stages - 1);
+    if (B < 1 || H < div || W < div || H % div || W % div)
+        return fail(TS2D_ERR_INVALID, "shape B=%d H=%d W=%d: H and W must be positive multiples of %d", B, H, W, div);
+    if ((H / div) * (W / div) <= 1)   // torch InstanceNorm2d raises "Expected more than 1 spatial element" here too
+        return fail(TS2D_ERR_INVALID, "shape %dx%d leaves a single bottleneck pixel: InstanceNorm needs more than 1 spatial element", H, W);
+    if ((long long)B * H * W >= (1LL << 31)) return fail(TS2D_ERR_INVALID, "B*H*W = %lld exceeds 2^31 pixels per call", (long long)B * H * W);
+    return ensure_workspace(e, B, H, W);
+}
+
+int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W, float* logits, uint32_t* mask_packed,
+                        int on_device, void* stream) {
+    if (!e || !input) return fail(TS2D_ERR_INVALID, "ts2d_engine_forward: null argument");
+    if (!e->weights_ready) return fail(TS2D_ERR_STATE, "ts2d_engine_forward: weights not loaded (create with weights, or broadcast + ts2d_engine_weights_ready)");
+    if (!logits && !mask_packed) return fail(TS2D_ERR_INVALID, "ts2d_engine_forward: both outputs are null");
+    if (mask_packed && (W % 32 || (H * W) % 64)) return fail(TS2D_ERR_INVALID, "packed mask output needs W %% 32 == 0 (W = %d)", W);
+    TRY(ts2d_engine_reserve(e, B, H, W));
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
+    const int K = e->arch.num_classes;
+    if (on_device) return run_forward(e, input, B, H, W, logits, mask_packed, st);
+    // host buffers: staged through the workspace, synchronous
+    HIP_TRY(hipMemcpyAsync(e->d_in_stage, input, (size_t)B * e->arch.input_channels * H * W * sizeof(float), hipMemcpyHostToDevice, st));
+    TRY(run_forward(e, e->d_in_stage, B, H, W, logits ? e->d_logit_stage : nullptr, mask_packed ? e->d_mask_stage : nullptr, st));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, e->d_logit_stage, (size_t)B * K * H * W * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (mask_packed) HIP_TRY(hipMemcpyAsync(mask_packed, e->d_mask_stage, (size_t)B * K * H * (W / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return TS2D_OK;
+}
+
+int ts2d_engine_set_profiling(ts2d_engine* e, int enable) {
+    if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_profiling: null engine");
+    e->profiling = enable != 0;
+    return TS2D_OK;
+}
+
+int ts2d_engine_num_ops(ts2d_engine* e) { return e ? (int)e->n_launched : 0; }
+
+const char* ts2d_engine_op_name(ts2d_engine* e, int op) {
+    if (!e || op < 0 || (size_t)op >= e->n_launched) return "";
+    return e->launches[op].name.c_str();
+}
+
+int ts2d_engine_op_times(ts2d_engine* e, float* ms, int n_ops) {
+    if (!e || !ms) return fail(TS2D_ERR_INVALID, "ts2d_engine_op_times: null argument");
+    if ((size_t)n_ops > e->n_launched) n_ops = (int)e->n_launched;
+    for (int i = 0; i < n_ops; ++i) {
+        HIP_TRY(hipEventSynchronize(e->launches[i].e1));
+        HIP_TRY(hipEventElapsedTime(&ms[i], e->launches[i].e0, e->launches[i].e1));
+    }
+    return TS2D_OK;
+}
+
+size_t ts2d_engine_device_bytes(ts2d_engine* e) { return e ? e->weight_floats * sizeof(float) + e->ws_bytes : 0; }
+
+int ts2d_engine_destroy(ts2d_engine* e) {
+    if (!e) return TS2D_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (Launch& l : e->launches) { if (l.e0) (void)hipEventDestroy(l.e0); if (l.e1) (void)hipEventDestroy(l.e1); }
+    if (e->d_ws) (void)hipFree(e->d_ws);
+    if (e->d_weights) (void)hipFree(e->d_weights);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return TS2D_OK;
+}
+
+}  // extern "C"

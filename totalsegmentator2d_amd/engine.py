@@ -1,0 +1,149 @@
+"""``Engine`` - Python handle on one HIP engine (one sub-model / fold on one GPU).
+
+Thin wrapper over the C-ABI (include/ts2d_engine.h).  It replaces ``nnUNetPredictor.network`` (built at reference
+``ts2d/core/inference/nnu.py:164-165``, called inside ``predict_logits_from_preprocessed_data``, reference
+``ts2d/core/inference/prediction_worker.py:209``).  torch is optional: numpy host arrays always work, torch CUDA
+tensors are consumed zero-copy through their ``data_ptr()``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .arch import UNetArch
+
+
+def _desc(arch: UNetArch) -> _lib.ArchDesc:
+    arch.validate()
+    d = _lib.ArchDesc()
+    d.input_channels, d.num_classes, d.n_stages = arch.input_channels, arch.num_classes, arch.n_stages
+    for i, f in enumerate(arch.features_per_stage):
+        d.features[i] = int(f)
+    for i, c in enumerate(arch.n_conv_per_stage):
+        d.n_conv_enc[i] = int(c)
+    for i, c in enumerate(arch.n_conv_per_stage_decoder):
+        d.n_conv_dec[i] = int(c)
+    d.norm_eps, d.leaky_slope = arch.norm_eps, arch.leaky_slope
+    return d
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith('torch') and hasattr(x, 'data_ptr')
+
+
+class Engine:
+    def __init__(self, arch: UNetArch, blob: Optional[np.ndarray], device: int = 0):
+        """blob: fp32 weight blob (:func:`weights.pack_blob`) or None for a replica to be filled by broadcast."""
+        self.lib = _lib.load()
+        self.arch = arch
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        d = _desc(arch)
+        if blob is not None:
+            blob = np.ascontiguousarray(blob, dtype=np.float32)
+            _lib.check(self.lib.ts2d_engine_create(ctypes.byref(d), blob.ctypes.data, blob.size, self.device,
+                                                   ctypes.byref(self._h)), 'ts2d_engine_create')
+        else:
+            _lib.check(self.lib.ts2d_engine_create(ctypes.byref(d), None, 0, self.device, ctypes.byref(self._h)),
+                       'ts2d_engine_create')
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self.lib.ts2d_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, blob: np.ndarray):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        _lib.check(self.lib.ts2d_engine_load_weights(self._h, blob.ctypes.data, blob.size), 'ts2d_engine_load_weights')
+
+    def weight_buffer(self) -> Tuple[int, int]:
+        """(device pointer, bytes) of the packed weight arena - the RCCL broadcast payload."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _lib.check(self.lib.ts2d_engine_weight_buffer(self._h, ctypes.byref(p), ctypes.byref(n)), 'ts2d_engine_weight_buffer')
+        return int(p.value), int(n.value)
+
+    def weights_ready(self):
+        _lib.check(self.lib.ts2d_engine_weights_ready(self._h), 'ts2d_engine_weights_ready')
+
+    # ------------------------------------------------------------------ forward
+    def reserve(self, B: int, H: int, W: int):
+        _lib.check(self.lib.ts2d_engine_reserve(self._h, B, H, W), 'ts2d_engine_reserve')
+
+    def forward(self, x, logits=True, mask=False, out_logits=None, out_mask=None, stream: int = 0):
+        """x: [B,C,H,W] fp32, numpy (host) or torch CUDA tensor (device, zero-copy).
+        Returns (logits or None, packed mask or None) of the same kind as x."""
+        K = self.arch.num_classes
+        if _is_torch(x):
+            import torch
+            if not x.is_cuda:
+                raise RuntimeError("torch input must live on the GPU (pass numpy for host data)")
+            x = x.contiguous()
+            if x.dtype != torch.float32:
+                raise RuntimeError(f"input must be float32, found {x.dtype}")
+            B, C, H, W = x.shape
+            self._check_shape(C, W, mask)
+            if logits and out_logits is None:
+                out_logits = torch.empty((B, K, H, W), dtype=torch.float32, device=x.device)
+            if mask and out_mask is None:
+                out_mask = torch.empty((B, K, H, W // 32), dtype=torch.int32, device=x.device)
+            if stream == 0:
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(self.lib.ts2d_engine_forward(
+                self._h, x.data_ptr(), B, H, W, out_logits.data_ptr() if logits else None,
+                out_mask.data_ptr() if mask else None, 1, ctypes.c_void_p(stream)), 'ts2d_engine_forward')
+            return (out_logits if logits else None), (out_mask if mask else None)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        B, C, H, W = x.shape
+        self._check_shape(C, W, mask)
+        if logits and out_logits is None:
+            out_logits = np.empty((B, K, H, W), dtype=np.float32)
+        if mask and out_mask is None:
+            out_mask = np.empty((B, K, H, W // 32), dtype=np.uint32)
+        _lib.check(self.lib.ts2d_engine_forward(
+            self._h, x.ctypes.data, B, H, W, out_logits.ctypes.data if logits else None,
+            out_mask.ctypes.data if mask else None, 0, None), 'ts2d_engine_forward')
+        return (out_logits if logits else None), (out_mask if mask else None)
+
+    def _check_shape(self, C, W, mask):
+        if C != self.arch.input_channels:
+            raise RuntimeError(f"input has {C} channels, the model expects {self.arch.input_channels}")
+        if mask and W % 32:
+            raise RuntimeError("packed mask output needs W % 32 == 0")
+
+    # ------------------------------------------------------------------ profiling
+    def set_profiling(self, on: bool):
+        _lib.check(self.lib.ts2d_engine_set_profiling(self._h, int(on)), 'ts2d_engine_set_profiling')
+
+    def op_times(self) -> Dict[str, float]:
+        """ms per launch of the LAST forward (HIP events on the launch stream), program order."""
+        n = self.lib.ts2d_engine_num_ops(self._h)
+        ms = (ctypes.c_float * max(n, 1))()
+        _lib.check(self.lib.ts2d_engine_op_times(self._h, ms, n), 'ts2d_engine_op_times')
+        return {self.lib.ts2d_engine_op_name(self._h, i).decode(): float(ms[i]) for i in range(n)}
+
+    def device_bytes(self) -> int:
+        return int(self.lib.ts2d_engine_device_bytes(self._h))
+
+
+def unpack_mask(packed: np.ndarray, W: int) -> np.ndarray:
+    """[.., W/32] uint32 -> [.., W] uint8 {0,1}."""
+    p = np.asarray(packed).view(np.uint32)
+    bits = (p[..., None] >> np.arange(32, dtype=np.uint32)) & np.uint32(1)
+    return bits.reshape(p.shape[:-1] + (W,)).astype(np.uint8)
