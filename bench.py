@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py - BASELINE.json metric: 2-ch 512x512 slices/sec on N MI355X (config 2: synthetic batch=64, one ts2d-v2
+sub-model (K=18), fp32).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one forward pass of the hot path (the whole PlainConvUNet, input NCHW -> fp32 logits NCHW + packed masks)
+over one batch of 64 synthetic slices per GPU, inputs already resident in HBM.  Slices shard over ranks with no
+data-path collective (weak scaling); weights are broadcast once from rank 0 with RCCL before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0
+
+
+def host_cores() -> int:
+    """Threads for the CPU baseline: the process's CPU share (affinity mask, cgroup quota), capped at 16 - the
+    per-GPU host share of the pool's boxes (a 256-thread pool on a 16-core share ran 30x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get('TS2D_CPU_THREADS', 16))))
+
+
+def cpu_baseline(arch, sd, budget_s: float = 20.0):
+    """The oracle (torch-CPU restatement = the ATen kernels the reference CPU path runs), B = 1 per call like the
+    reference, all host cores, on a bounded sample of the same workload."""
+    import torch
+    from oracle import torch_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    x = torch.randn(1, arch.input_channels, 512, 512)
+    O.unet_forward(arch, sd, x)                      # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 3 or (time.time() - t0 < budget_s and n < 64):
+        O.unet_forward(arch, sd, x)
+        n += 1
+    dt = time.time() - t0
+    return {'value': round(n / dt, 3), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} single-slice (B=1, no mirroring) 2x512x512 forwards of the same network, torch-CPU oracle, '
+                      f'{torch.get_num_threads()} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=64, help='slices per GPU per step (config 2: 64)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from totalsegmentator2d_amd import parallel, weights
+    from totalsegmentator2d_amd.arch import UNetArch, OP_CONV3X3
+    from totalsegmentator2d_amd.engine import Engine
+
+    rank, local_rank, world = parallel.env_rank_world()
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    multi = world > 1
+    if multi:
+        parallel.init_process_group('nccl')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    arch = UNetArch.canonical(input_channels=2, num_classes=18)            # one ts2d-v2 sub-model (cardiac, K = 18)
+    B, H, W = args.batch, 512, 512
+    sd = None
+    if rank == 0:
+        sd = weights.synthetic_state_dict(arch, seed=1)                    # He-normal, BASELINE.md section 4
+        engine = Engine(arch, weights.pack_blob(arch, sd), device=local_rank)
+    else:
+        engine = Engine(arch, None, device=local_rank)
+    bcast_ms = None
+    if multi:
+        dist.barrier()
+        t0 = time.time()
+        parallel.broadcast_engine_weights(engine, src=0)                   # one RCCL broadcast over xGMI
+        bcast_ms = (time.time() - t0) * 1e3
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.randn(B, 2, H, W, device=dev, generator=gen)                 # synthetic N(0,1) = post-z-score statistics
+    logits = torch.empty(B, arch.num_classes, H, W, device=dev)
+    mask = torch.empty(B, arch.num_classes, H, W // 32, dtype=torch.int32, device=dev)
+    engine.reserve(B, H, W)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        engine.forward(x, logits=True, mask=True, out_logits=logits, out_mask=mask, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    profile = not args.no_profile and rank == 0
+    if profile:
+        engine.set_profiling(True)
+    op_ms = {}
+    torch.cuda.synchronize(dev)
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if profile:                                                        # HIP events on the launch stream, read per step
+            for k, v in engine.op_times().items():
+                op_ms[k] = op_ms.get(k, 0.0) + v
+    torch.cuda.synchronize(dev)
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+
+    if rank == 0:
+        work = arch.work(H, W)
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        out = {
+            'metric': '2-ch 512x512 slices/sec', 'value': round(value, 2), 'unit': 'slices/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: synthetic batch=64 2x512x512, one ts2d-v2 sub-model '
+                                   '(canonical 8-stage PlainConvUNet, K=18), fp32, logits + packed masks out',
+                       'batch_per_gpu': B, 'global_batch': world * B, 'H': H, 'W': W, 'K': arch.num_classes,
+                       'parallelism': f'slice-dp{world}', 'gflop_per_slice': round(work['flops'] / 1e9, 2),
+                       'act_mb_per_slice': round(work['act_bytes'] / 1e6, 1)},
+            'tflops': round(value * work['flops'] / 1e12, 2),
+        }
+        if bcast_ms is not None:
+            out['weight_broadcast_ms'] = round(bcast_ms, 2)
+        if profile and op_ms:
+            # dominant kernel = the implicit-GEMM conv (conv_mfma_f32, TAPS=9): all 30 Conv2d 3x3 launches of a step
+            per = {o['name']: 2.0 * m['macs'] for o, m in zip(arch.program(), work['per_layer']) if o['op'] == OP_CONV3X3}
+            conv_ms = sum(v for k, v in op_ms.items() if k in per) / args.steps
+            conv_flops = sum(per.values()) * B
+            achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get('conv_mfma_f32_hbm_bytes_per_step')
+                except Exception:
+                    traffic = None
+            out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                               'kernel': 'conv_mfma_f32<TAPS=9> (30 launches/step)',
+                               'kernel_ms_per_step': round(conv_ms, 3),
+                               'kernel_share_of_step': round(conv_ms / ms_per_step, 4),
+                               'whole_step_hbm_frac_layerwise': round(value / world * work['act_bytes'] / 1e9 / PEAK_HBM_GBS, 4)}
+            top = sorted(op_ms.items(), key=lambda kv: -kv[1])[:8]
+            out['top_ops_ms'] = {k: round(v / args.steps, 3) for k, v in top}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(arch, sd)
+        print(json.dumps(out), flush=True)
+    engine.close()
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

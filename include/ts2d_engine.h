@@ -95,6 +95,12 @@ int ts2d_engine_num_ops(ts2d_engine* e);
 const char* ts2d_engine_op_name(ts2d_engine* e, int op);
 int ts2d_engine_op_times(ts2d_engine* e, float* ms, int n_ops);
 
+/* Test/debug accessor (not on the product path): copies activation tensor `name` ("enc0.c1", "dec3.up", ... - the
+ * op names of ts2d_engine_op_name) of the LAST forward to host as NCHW fp32 [B,C,h,w], with the InstanceNorm +
+ * LeakyReLU that its consumer applies on load already applied (i.e. what torch holds after the block).
+ * `capacity` = floats available in out; *dims receives {B, C, h, w}.  Synchronises the engine. */
+int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_t capacity, int32_t dims[4]);
+
 /* Bytes of device memory currently held (weights + workspace). */
 size_t ts2d_engine_device_bytes(ts2d_engine* e);
 

@@ -1,0 +1,88 @@
+"""Generates tests/golden/*.npz with the torch-CPU oracle (oracle/torch_oracle.py), run in the build container.
+
+The reference pins no numerical result for this path, so the vectors are produced by the SAME
+ATen CPU kernels the reference's CPU path dispatches to, on inputs/weights from the portable PRNG.  Re-run:
+    python tests/gen_golden.py            (about two minutes; the canonical-net case dominates)
+Fixtures are data only: inputs are regenerated from seeds, outputs are stored.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import torch_oracle as O                      # noqa: E402
+from tests import cases                                   # noqa: E402
+from totalsegmentator2d_amd import prng, weights          # noqa: E402
+from totalsegmentator2d_amd.arch import UNetArch          # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    import torch
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    # (i)+(ii) small architectures: full logits + every intermediate activation (per-kernel parity K1..K7)
+    for name, (arch, B, H, W, seed) in cases.SMALL_CASES.items():
+        sd = weights.synthetic_state_dict(arch, seed)
+        x = cases.make_input(arch, B, H, W, seed)
+        y, inter = O.unet_forward(arch, sd, x, return_intermediates=True)
+        y = y.numpy()
+        rec = {'logits': y, 'mask_packed': O.pack_mask(O.logits_to_mask(y).numpy()) if W % 32 == 0 else np.zeros(0, np.uint32)}
+        if cases.KEEP_INTERMEDIATES.get(name, False):
+            rec.update({f'inter/{k}': v.numpy() for k, v in inter.items()})
+        np.savez_compressed(os.path.join(OUT, f'{name}.npz'), **rec)
+        print(name, y.shape, float(np.abs(y).max()))
+    # (iii) canonical net, one 2x512x512 slice: strided samples + checksums + mask hash
+    arch = UNetArch.canonical()
+    sd = weights.synthetic_state_dict(arch, 1)
+    x = cases.make_input(arch, 1, 512, 512, 1)
+    y = O.unet_forward(arch, sd, x).numpy()
+    mask = O.logits_to_mask(y).numpy()
+    np.savez_compressed(os.path.join(OUT, 'canonical_512.npz'),
+                        samples=y[:, :, ::8, ::8].copy(), sum=np.float64(y.astype(np.float64).sum()),
+                        abs_sum=np.float64(np.abs(y.astype(np.float64)).sum()), vmax=y.max(), vmin=y.min(),
+                        mask_count=np.int64(mask.sum()), mask_rows=O.pack_mask(mask)[:, :, ::8].copy(),
+                        mask_sha256=np.frombuffer(hashlib.sha256(O.pack_mask(mask).tobytes()).digest(), dtype=np.uint8))
+    print('canonical', float(np.abs(y).max()), int(mask.sum()))
+    # (iv) sliding-window steps + gaussian
+    steps = {}
+    for img in (337, 512, 644, 700, 1024, 513, 767, 768, 769):
+        for st in (0.5, 1.0, 0.25):
+            steps[f'{img}_{st}'] = np.array(O.sliding_window_steps((max(img, 512),), (512,), st)[0], dtype=np.int64)
+    g = O.compute_gaussian((512, 512)).numpy()
+    g2 = O.compute_gaussian((64, 96)).numpy()
+    np.savez_compressed(os.path.join(OUT, 'sliding_window.npz'), g512_diag=np.diag(g).copy(), g512_row0=g[0].copy(),
+                        g512_centre=g[256].copy(), g64x96=g2, **{f'steps/{k}': v for k, v in steps.items()})
+    # sliding-window + mirroring + fp16 aggregation end to end on a small net (A2-A5)
+    for name, (arch, shape, patch, step, mirror, folds, seed) in cases.SW_CASES.items():
+        sds = [weights.synthetic_state_dict(arch, seed + f) for f in range(folds)]
+        data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
+        out = O.predict_logits(arch, sds, data, patch, step, mirror).numpy()
+        np.savez_compressed(os.path.join(OUT, f'{name}.npz'), logits_f16=out)
+        print(name, out.shape, out.dtype)
+    # (v) real-data plumbing: the reference's own sample assets (data files) + z-scored checksums
+    adir = os.path.join(OUT, 'assets')
+    os.makedirs(adir, exist_ok=True)
+    ref_assets = '/root/reference/assets'
+    for f in ('sample_s0616.nrrd', 'sample_s0332.nrrd', 'sample_s0521.nrrd', 'sample_chexpert.nrrd'):
+        if os.path.exists(os.path.join(ref_assets, f)):
+            shutil.copyfile(os.path.join(ref_assets, f), os.path.join(adir, f))
+    from totalsegmentator2d_amd import nrrd
+    img = nrrd.read(os.path.join(adir, 'sample_s0616.nrrd'))
+    a = np.moveaxis(np.asarray(img.array), -1, 0).astype(np.float32)
+    z = np.stack([O.zscore(a[c]) for c in range(a.shape[0])])
+    np.savez_compressed(os.path.join(OUT, 'sample_s0616_zscore.npz'), shape=np.array(z.shape),
+                        sum=np.float64(z.astype(np.float64).sum()), abs_sum=np.float64(np.abs(z.astype(np.float64)).sum()),
+                        samples=z[:, ::16, ::16].copy(), raw_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(img.array).tobytes()).digest(), dtype=np.uint8))
+    print('done')
+
+
+if __name__ == '__main__':
+    main()

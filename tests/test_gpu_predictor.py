@@ -1,0 +1,57 @@
+"""Drop-in predictor on the GPU: sliding window + mirroring + fold ensemble through the HIP engine, and BASELINE
+config 1 (the reference's sample_s0616.nrrd, 2 tiles x 4 mirror passes)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+from tests.conftest import golden, blob_for, GOLDEN
+from totalsegmentator2d_amd import prng
+from totalsegmentator2d_amd.arch import UNetArch
+from totalsegmentator2d_amd.predictor import HIPnnUNetPredictor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', list(cases.SW_CASES))
+def test_sliding_window_goldens(name):
+    arch, shape, patch, step, mirror, folds, seed = cases.SW_CASES[name]
+    blobs = [blob_for(arch, seed + f)[1] for f in range(folds)]
+    data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
+    p = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None)
+    p.manual_initialization(arch, blobs, patch, inference_allowed_mirroring_axes=mirror)
+    try:
+        out = p.predict_logits_from_preprocessed_data(data).cpu().numpy()
+    finally:
+        p.close()
+    g = golden(name)['logits_f16']
+    assert out.dtype == np.float16 and out.shape == g.shape
+    # reference end-of-pipeline logits are float16 (about 3 significant digits): allow 2 half-ulps at |x| <= 8
+    assert np.abs(out.astype(np.float32) - g.astype(np.float32)).max() <= 1.6e-2
+    assert (out != g).mean() < 0.05
+
+
+def test_config1_sample_s0616_canonical_net():
+    """BASELINE config 1: real 2-channel coronal projection -> z-score -> [2,1,644,337] -> pad to 512 wide -> 2 tiles
+    x 4 mirror passes -> fp16 aggregation; synthetic seeded weights (the Zenodo weights are not available offline)."""
+    from oracle import torch_oracle as O
+    arch = UNetArch.canonical()
+    sd, blob = blob_for(arch, 1)
+    p = HIPnnUNetPredictor()                      # reference defaults: step 0.5, mirroring on (wrapper.py:65-66)
+    p.manual_initialization(arch, [blob], (512, 512))
+    try:
+        pre = p.configuration_manager.preprocessor_class(verbose=False)
+        data, _, props = pre.run_case([os.path.join(GOLDEN, 'assets', 'sample_s0616.nrrd')], None, p.plans_manager,
+                                      p.configuration_manager, p.dataset_json)
+        assert data.shape == (2, 1, 644, 337)
+        out = p.predict_logits_from_preprocessed_data(data).cpu().numpy()
+    finally:
+        p.close()
+    assert out.shape == (18, 1, 644, 337) and out.dtype == np.float16
+    ref = O.predict_logits(arch, [sd], data, (512, 512), 0.5, (0, 1)).numpy()
+    d = np.abs(out.astype(np.float32) - ref.astype(np.float32))
+    assert d.max() <= 1.6e-2 and (out != ref).mean() < 0.05
+    seg = (out.astype(np.float32) > 1.5 * 2.0 ** -24)
+    seg_ref = O.logits_to_mask(ref).numpy().astype(bool)
+    assert (seg != seg_ref).mean() < 1e-3

@@ -1,0 +1,60 @@
+"""Host logic of the drop-in predictor on CPU: tiling, mirroring, fp16 Gaussian aggregation, fold ensemble.
+The network is injected (torch oracle) through the predictor's test hook, so no GPU is needed; the product path
+always builds HIP engines (tests/test_gpu_predictor.py)."""
+import numpy as np
+import pytest
+
+from tests import cases
+from tests.conftest import golden, blob_for
+from oracle import torch_oracle as O
+from totalsegmentator2d_amd import prng, weights
+from totalsegmentator2d_amd.predictor import HIPnnUNetPredictor
+
+
+def _predictor(arch, sds, patch, step, mirror):
+    def net(batch, fold):   # row by row (B = 1) like upstream, so torch picks the same kernels as in the oracle run
+        return np.concatenate([O.unet_forward(arch, sds[fold], batch[i:i + 1]).numpy() for i in range(batch.shape[0])])
+    p = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, network=net)
+    p.manual_initialization(arch, [weights.pack_blob(arch, sd) for sd in sds], patch,
+                            inference_allowed_mirroring_axes=mirror)
+    return p
+
+
+@pytest.mark.parametrize('name', list(cases.SW_CASES))
+def test_predictor_host_logic_is_bit_faithful_to_upstream_aggregation(name):
+    arch, shape, patch, step, mirror, folds, seed = cases.SW_CASES[name]
+    sds = [blob_for(arch, seed + f)[0] for f in range(folds)]
+    data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
+    p = _predictor(arch, sds, patch, step, mirror)
+    out = p.predict_logits_from_preprocessed_data(data)
+    out = out.cpu().numpy() if hasattr(out, 'cpu') else out
+    ref = O.predict_logits(arch, sds, data, patch, step, mirror).numpy()
+    assert out.dtype == np.float16 and out.shape == ref.shape == golden(name)['logits_f16'].shape
+    # same per-tile network outputs (same torch kernels) => the numpy fp16 emulation must equal torch's half arithmetic
+    assert np.array_equal(out, ref)
+
+
+def test_predictor_duck_type_surface():
+    """What reference prediction_worker.py touches."""
+    arch = cases.unet(2, (32, 32), 2)
+    sd = weights.synthetic_state_dict(arch, 3)
+    p = _predictor(arch, [sd], (32, 32), 0.5, (0, 1))
+    assert 'nnUNetPredictor' in type(p).__name__                               # prediction_worker.py:103
+    assert tuple(p.configuration_manager.patch_size) == (32, 32) and len(p.configuration_manager.spacing) == 2
+    assert p.dataset_json['file_ending'] == '.nrrd' and len(p.dataset_json['channel_names']) == 2
+    assert p.device.type == 'cuda' and p.verbose is False
+    assert hasattr(p.configuration_manager.preprocessor_class(verbose=False), 'run_case')
+    with pytest.raises(AssertionError):
+        p.predict_sliding_window_return_logits(np.zeros((2, 32, 32), np.float32))   # must be 4-D [C,Z,H,W]
+    with pytest.raises(RuntimeError):
+        HIPnnUNetPredictor(device=type('D', (), {'type': 'cpu', 'index': None})())  # no CPU fallback
+
+
+def test_pad_and_mirror_combos():
+    from totalsegmentator2d_amd import sliding_window as sw
+    x = np.arange(2 * 1 * 5 * 7, dtype=np.float32).reshape(2, 1, 5, 7)
+    p, rev = sw.pad_nd_image(x, (8, 8))
+    assert p.shape == (2, 1, 8, 8) and np.array_equal(p[rev], x) and p[0, 0, 0, 0] == 0
+    assert rev[2] == slice(1, 6) and rev[3] == slice(0, 7)                       # below = diff // 2
+    assert sw.mirror_combos((0, 1)) == [(), (2,), (3,), (2, 3)] and sw.mirror_combos(None) == [()]
+    assert sw.tile_slicers((644, 512), (512, 512), 0.5, 1) == [(0, 0, 0), (0, 132, 0)]

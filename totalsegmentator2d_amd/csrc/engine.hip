@@ -74,6 +74,7 @@ struct ts2d_engine {
     hipStream_t stream = nullptr;
     bool profiling = false;
     std::vector<Launch> launches; size_t n_launched = 0;
+    int lastB = 0, lastH = 0, lastW = 0; hipStream_t last_stream = nullptr;
 };
 
 namespace {
@@ -326,6 +327,7 @@ int prof_end(ts2d_engine* e, hipStream_t st) {
 int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st) {
     const ts2d_arch_desc& a = e->arch;
     e->n_launched = 0;
+    e->lastB = B; e->lastH = H; e->lastW = W; e->last_stream = st;
     {   // boundary layout change NCHW -> NHWC (channels zero-padded to 8)
         const long long total = (long long)B * H * W;
         TRY(prof_begin(e, "input.nhwc", st));
@@ -508,6 +510,34 @@ int ts2d_engine_op_times(ts2d_engine* e, float* ms, int n_ops) {
         HIP_TRY(hipEventSynchronize(e->launches[i].e1));
         HIP_TRY(hipEventElapsedTime(&ms[i], e->launches[i].e0, e->launches[i].e1));
     }
+    return TS2D_OK;
+}
+
+int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_t capacity, int32_t dims[4]) {
+    if (!e || !name || !out || !dims) return fail(TS2D_ERR_INVALID, "ts2d_engine_debug_tensor: null argument");
+    const int ti = tensor_index(e, name);
+    if (ti < 0 || !e->lastB) return fail(TS2D_ERR_INVALID, "no tensor '%s' (or no forward has run)", name);
+    const Tensor& t = e->tensors[ti];
+    const int B = e->lastB, h = e->lastH >> t.level, w = e->lastW >> t.level, C = t.C;
+    dims[0] = B; dims[1] = C; dims[2] = h; dims[3] = w;
+    const size_t n = (size_t)B * C * h * w;
+    if (capacity < n) return fail(TS2D_ERR_INVALID, "tensor '%s' needs %zu floats, capacity is %zu", name, n, capacity);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->last_stream ? e->last_stream : e->stream));
+    std::vector<float> raw(n), sc, sh;
+    HIP_TRY(hipMemcpy(raw.data(), t.data, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (t.normed) {
+        sc.resize((size_t)B * C); sh.resize((size_t)B * C);
+        HIP_TRY(hipMemcpy(sc.data(), t.scale, sc.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(sh.data(), t.shift, sh.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < h * w; ++p)
+            for (int c = 0; c < C; ++c) {
+                float v = raw[((size_t)b * h * w + p) * C + c];
+                if (t.normed) { v = v * sc[(size_t)b * C + c] + sh[(size_t)b * C + c]; v = v > 0.f ? v : v * e->arch.leaky_slope; }
+                out[((size_t)b * C + c) * h * w + p] = v;
+            }
     return TS2D_OK;
 }
 

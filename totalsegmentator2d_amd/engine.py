@@ -138,6 +138,15 @@ class Engine:
         _lib.check(self.lib.ts2d_engine_op_times(self._h, ms, n), 'ts2d_engine_op_times')
         return {self.lib.ts2d_engine_op_name(self._h, i).decode(): float(ms[i]) for i in range(n)}
 
+    def debug_tensor(self, name: str, capacity: int = 1 << 26) -> np.ndarray:
+        """Test accessor: activation `name` of the last forward as torch would hold it (NCHW, norm+act applied)."""
+        out = np.empty(capacity, dtype=np.float32)
+        dims = (ctypes.c_int32 * 4)()
+        _lib.check(self.lib.ts2d_engine_debug_tensor(self._h, name.encode(), out.ctypes.data, out.size, ctypes.byref(dims)),
+                   'ts2d_engine_debug_tensor')
+        shp = tuple(int(d) for d in dims)
+        return out[:int(np.prod(shp))].reshape(shp).copy()
+
     def device_bytes(self) -> int:
         return int(self.lib.ts2d_engine_device_bytes(self._h))
 

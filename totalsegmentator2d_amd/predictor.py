@@ -1,0 +1,207 @@
+"""``HIPnnUNetPredictor`` - the drop-in for the duck-typed predictor the reference worker consumes.
+
+The reference accepts any object whose type name contains ``nnUNetPredictor`` (or a zero-argument callable returning
+one): ``ts2d/core/inference/prediction_worker.py:103-114``.  The members it touches are mirrored here with the same
+names and argument meaning:
+
+* ``.configuration_manager.patch_size`` / ``.spacing`` / ``.preprocessor_class(verbose=)``  (prediction_worker.py:76-77,194)
+* ``.dataset_json`` (``channel_names``, ``file_ending``, ``labels``)                           (prediction_worker.py:78,180,230)
+* ``.plans_manager``, ``.verbose``, ``.device.type``                                         (prediction_worker.py:194-207)
+* ``.predict_logits_from_preprocessed_data(data[C,1,H,W]) -> Tensor[K,1,H,W]`` with ``.cpu()`` (prediction_worker.py:206-209)
+* ``initialize_from_trained_model_folder(model_dir, folds, checkpoint_name)``                (nnu.py:165)
+* ctor kwargs ``tile_step_size, use_mirroring, verbose, allow_tqdm, device, perform_everything_on_device`` (nnu.py:152-163)
+
+What changes underneath: ``network(x)`` is the HIP engine (C-ABI, include/ts2d_engine.h); all tiles x mirror variants
+of a case are submitted as ONE batch instead of B=1 calls; the Gaussian/fp16 aggregation follows upstream bit for
+bit (float16 accumulators) so that end-of-pipeline logits are comparable with the reference's.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+from types import SimpleNamespace
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import sliding_window as sw
+from .arch import UNetArch
+
+
+class _Device:
+    """``torch.device``-like (``.type``) without importing torch."""
+    def __init__(self, index: int):
+        self.type, self.index = 'cuda', index
+
+    def __repr__(self):
+        return f"device(type='cuda', index={self.index})"
+
+
+class HIPnnUNetPredictor:
+    def __init__(self, tile_step_size: float = 0.5, use_gaussian: bool = True, use_mirroring: bool = True,
+                 perform_everything_on_device: bool = True, device=None, verbose: bool = False,
+                 verbose_preprocessing: bool = False, allow_tqdm: bool = True, max_batch: int = 64,
+                 network: Optional[Callable[[np.ndarray], np.ndarray]] = None):
+        """``network``: test hook - a callable [B,C,h,w] -> [B,K,h,w] used INSTEAD of creating HIP engines (host-logic
+        unit tests on machines without a GPU).  The product path never passes it."""
+        self.tile_step_size = tile_step_size
+        self.use_gaussian = use_gaussian
+        self.use_mirroring = use_mirroring
+        self.perform_everything_on_device = perform_everything_on_device
+        self.verbose = verbose
+        self.verbose_preprocessing = verbose_preprocessing
+        self.allow_tqdm = allow_tqdm
+        self.max_batch = int(max_batch)
+        idx = 0
+        if device is not None:
+            idx = getattr(device, 'index', device)
+            idx = 0 if idx is None else int(idx)
+            if getattr(device, 'type', 'cuda') != 'cuda':
+                raise RuntimeError("HIPnnUNetPredictor runs on an MI355X only; there is no CPU fallback")
+        self.device = _Device(idx)
+        self._network_override = network
+        self.engines: list = []
+        self.arch: Optional[UNetArch] = None
+        self.plans_manager = None
+        self.configuration_manager = None
+        self.dataset_json = None
+        self.allowed_mirroring_axes = None
+        self.list_of_parameters: List[np.ndarray] = []
+        self.label_manager = None
+
+    # ------------------------------------------------------------------ initialisation
+    def manual_initialization(self, arch: UNetArch, fold_blobs: Sequence[np.ndarray], patch_size: Sequence[int],
+                              spacing: Sequence[float] = (1.5, 1.5), dataset_json: Optional[dict] = None,
+                              plans: Optional[dict] = None, configuration: str = '2d',
+                              inference_allowed_mirroring_axes: Optional[Sequence[int]] = (0, 1)):
+        from .preprocess import DefaultPreprocessor
+        self.arch = arch
+        self.list_of_parameters = [np.ascontiguousarray(b, dtype=np.float32) for b in fold_blobs]
+        self.allowed_mirroring_axes = tuple(inference_allowed_mirroring_axes) if inference_allowed_mirroring_axes else None
+        self.dataset_json = dataset_json or {
+            'channel_names': {str(i): f'ch{i}' for i in range(arch.input_channels)},
+            'labels': {'background': 0, **{f'label{i + 1}': i + 1 for i in range(arch.num_classes)}},
+            'file_ending': '.nrrd', 'multilabel': True}
+        self.plans_manager = SimpleNamespace(plans=plans or {}, transpose_forward=[0, 1, 2], transpose_backward=[0, 1, 2])
+        self.configuration_manager = SimpleNamespace(
+            patch_size=list(patch_size), spacing=list(spacing), preprocessor_class=DefaultPreprocessor,
+            normalization_schemes=['ZScoreNormalization'] * arch.input_channels,
+            use_mask_for_norm=[False] * arch.input_channels, configuration=configuration)
+        self._create_engines()
+
+    def initialize_from_trained_model_folder(self, model_training_output_dir: str, use_folds, checkpoint_name: str = 'checkpoint_final.pth'):
+        """Reads ``dataset.json`` / ``plans.json`` / ``fold_X/<checkpoint_name>`` exactly where upstream does."""
+        from . import weights as W
+        with open(os.path.join(model_training_output_dir, 'dataset.json')) as f:
+            dataset_json = json.load(f)
+        with open(os.path.join(model_training_output_dir, 'plans.json')) as f:
+            plans = json.load(f)
+        if use_folds is None or use_folds == 'auto':
+            use_folds = sorted(int(m.group(1)) for m in (re.match(r'fold_(\d+)$', d) for d in os.listdir(model_training_output_dir)) if m)
+        if isinstance(use_folds, (str, int)):
+            use_folds = [use_folds]
+        blobs, mirror, configuration = [], None, None
+        n_in = len(dataset_json['channel_names'])
+        labels = dataset_json['labels']
+        multilabel = bool(dataset_json.get('multilabel', dataset_json.get('multiclass', False)))
+        n_fg = len([k for k, v in labels.items() if k != 'background' and v != 0])
+        n_heads = n_fg if multilabel else len(labels)
+        for i, f in enumerate(use_folds):
+            f = int(f) if f != 'all' else f
+            sd, mirror_axes, init_args = W.load_checkpoint(os.path.join(model_training_output_dir, f'fold_{f}', checkpoint_name))
+            if i == 0:
+                configuration = init_args.get('configuration', '2d')
+                mirror = mirror_axes
+                arch = UNetArch.from_plans(plans, configuration, n_in, n_heads)
+            blobs.append(W.pack_blob(arch, sd))
+        cfg = plans['configurations'][configuration]
+        self.manual_initialization(arch, blobs, cfg['patch_size'], cfg.get('spacing', (1.0, 1.0)), dataset_json, plans,
+                                   configuration, mirror)
+        self.plans_manager.transpose_forward = plans.get('transpose_forward', [0, 1, 2])
+        self.plans_manager.transpose_backward = plans.get('transpose_backward', [0, 1, 2])
+        self.configuration_manager.normalization_schemes = cfg.get('normalization_schemes', self.configuration_manager.normalization_schemes)
+        self.configuration_manager.use_mask_for_norm = cfg.get('use_mask_for_norm', self.configuration_manager.use_mask_for_norm)
+
+    def _create_engines(self):
+        if self._network_override is not None:
+            return
+        from .engine import Engine            # raises loudly if libts2d_engine.so is missing - no fallback
+        for e in self.engines:
+            e.close()
+        self.engines = [Engine(self.arch, blob, self.device.index) for blob in self.list_of_parameters]
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = []
+
+    # ------------------------------------------------------------------ inference
+    def _run_network(self, fold: int, batch: np.ndarray) -> np.ndarray:
+        if self._network_override is not None:
+            return np.asarray(self._network_override(batch, fold) if self._network_override.__code__.co_argcount > 1
+                              else self._network_override(batch), dtype=np.float32)
+        out = []
+        for a in range(0, batch.shape[0], self.max_batch):
+            lg, _ = self.engines[fold].forward(batch[a:a + self.max_batch], logits=True, mask=False)
+            out.append(lg)
+        return out[0] if len(out) == 1 else np.concatenate(out, 0)
+
+    def predict_sliding_window_return_logits(self, data: np.ndarray, fold: int = 0) -> np.ndarray:
+        """One fold: tiles x mirror variants -> one engine batch -> upstream's fp16 Gaussian aggregation.
+        data [C,Z,H,W] float32 -> float16 [K,Z,H,W]."""
+        patch = tuple(self.configuration_manager.patch_size)
+        data = np.asarray(data, dtype=np.float32)
+        if data.ndim != 4:
+            raise AssertionError('input_image must be a 4D np.ndarray or torch.Tensor (c, x, y, z)')
+        padded, revert = sw.pad_nd_image(data, patch)
+        C, Z, H, W = padded.shape
+        slicers = sw.tile_slicers((H, W), patch, self.tile_step_size, Z)
+        combos = sw.mirror_combos(self.allowed_mirroring_axes if self.use_mirroring else None)
+        if self.use_mirroring and self.allowed_mirroring_axes and max(self.allowed_mirroring_axes) > 1:
+            raise AssertionError('mirror_axes does not match the dimension of the input!')
+        nv = len(combos)
+        batch = np.empty((len(slicers) * nv, C, patch[0], patch[1]), dtype=np.float32)
+        for t, (d, sx, sy) in enumerate(slicers):
+            x = padded[:, d, sx:sx + patch[0], sy:sy + patch[1]]
+            for v, c in enumerate(combos):
+                batch[t * nv + v] = np.flip(x, [a - 1 for a in c]) if c else x      # tensor dim a of [1,C,h,w] = dim a-1 here
+        y = self._run_network(fold, batch)
+        K = y.shape[1]
+        g = sw.compute_gaussian(patch) if self.use_gaussian else np.ones(patch, dtype=np.float16)
+        logits = np.zeros((K, Z, H, W), dtype=np.float16)
+        n_pred = np.zeros((Z, H, W), dtype=np.float16)
+        for t, (d, sx, sy) in enumerate(slicers):
+            p = y[t * nv].copy()
+            for v in range(1, nv):
+                p += np.flip(y[t * nv + v], [a - 1 for a in combos[v]])
+            if nv > 1:
+                p /= np.float32(nv)
+            p = p.astype(np.float16)
+            if self.use_gaussian:
+                p = p * g
+            logits[:, d, sx:sx + patch[0], sy:sy + patch[1]] += p
+            n_pred[d, sx:sx + patch[0], sy:sy + patch[1]] += g
+        logits = logits / n_pred
+        if np.any(np.isinf(logits)):
+            raise RuntimeError('Encountered inf in predicted array. Aborting... If this problem persists, reduce '
+                               'value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits to fp32')
+        return logits[(slice(None),) + revert[1:]]
+
+    def predict_logits_from_preprocessed_data(self, data):
+        """Fold ensemble (upstream: sum over ``list_of_parameters`` then ``/= n``).  Accepts numpy or torch [C,1,H,W];
+        returns a torch CPU tensor (float16) when torch is importable so that the caller's ``.cpu()`` works."""
+        if hasattr(data, 'detach'):
+            data = data.detach().cpu().numpy()
+        n = max(1, len(self.list_of_parameters))
+        pred = None
+        for f in range(n):
+            p = self.predict_sliding_window_return_logits(data, f)
+            pred = p if pred is None else pred + p
+        if n > 1:
+            pred = pred / np.float16(n)
+        try:
+            import torch
+            return torch.from_numpy(np.ascontiguousarray(pred))
+        except ImportError:
+            return pred
