@@ -47,6 +47,15 @@ typedef struct {
     float leaky_slope;                      /* LeakyReLU negative_slope (0.01) */
 } ts2d_arch_desc;
 
+/* Arithmetic of the dense 3x3 contractions (storage, accumulation, statistics and I/O are fp32 in both modes):
+ *   TS2D_PRECISION_F32_EXACT       v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 FMA chain (157 TFLOP/s peak).
+ *   TS2D_PRECISION_F32_SPLIT_F16X3 (default) operands split into fp16 hi + lo (22 significant bits) and multiplied
+ *       as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation; measured as close to the fp64
+ *       truth as ATen's native fp32 conv on the canonical net.  Activations must stay below
+ *       65504 in magnitude (always true after InstanceNorm for |gamma| < 127). */
+#define TS2D_PRECISION_F32_EXACT 0
+#define TS2D_PRECISION_F32_SPLIT_F16X3 1
+
 typedef struct ts2d_engine ts2d_engine;
 
 /* Create an engine on HIP device `device`.
@@ -63,6 +72,9 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
 /* Replace the weights of an existing engine (fold switch: `network.load_state_dict(params)` in
  * predict_logits_from_preprocessed_data, reference call site prediction_worker.py:209). */
 int ts2d_engine_load_weights(ts2d_engine* e, const float* weights, size_t n_floats);
+
+/* Select the arithmetic mode (see TS2D_PRECISION_*); takes effect at the next forward. */
+int ts2d_engine_set_precision(ts2d_engine* e, int mode);
 
 /* Weight-broadcast hook: device pointer + byte size of the packed weight arena.  Rank 0 creates with
  * weights, the other ranks with NULL; all ranks broadcast this buffer (RCCL, root 0), then call

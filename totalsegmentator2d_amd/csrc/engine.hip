@@ -3,9 +3,11 @@
 // network built at ts2d/core/inference/nnu.py:164-165).  gfx950 only; no CPU fallback exists in this library.
 #include "../../include/ts2d_engine.h"
 #include "kernels.h"
+#include "kernels_f16x3.h"
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,6 +50,9 @@ struct Op {
     size_t blob_w, blob_b, blob_g, blob_be;     // offsets (floats) into the PyTorch-layout blob
     size_t dev_w, dev_b, dev_g, dev_be;         // offsets (floats) into the device weight arena
     size_t dev_w_floats;
+    bool split_ok = false;        // eligible for the split-fp16 kernel (3x3, stride 1, Cin % 16 == 0, not the net input)
+    size_t dev_wh = 0;            // offset (floats) of the split-fp16 weights in the arena
+    size_t dev_ws = 0;            // offset (floats) of 1 / (power-of-two pre-scale of the split weights)
 };
 
 struct Launch { std::string name; hipEvent_t e0 = nullptr, e1 = nullptr; };
@@ -67,6 +72,7 @@ struct ts2d_engine {
     size_t blob_floats = 0;
     float* d_weights = nullptr; size_t weight_floats = 0;
     bool weights_ready = false;
+    int precision = TS2D_PRECISION_F32_SPLIT_F16X3;
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
     float* d_part = nullptr;
@@ -165,14 +171,80 @@ int build_program(ts2d_engine* e) {
         op.dev_w = wo; wo = align_up(wo + op.dev_w_floats, 64);
         op.dev_b = wo; wo = align_up(wo + op.cout, 64);
         if (op.type == OP_CONV) { op.dev_g = wo; wo = align_up(wo + op.cout, 64); op.dev_be = wo; wo = align_up(wo + op.cout, 64); }
+        if (op.type == OP_CONV && op.src != 0 && ((op.stride == 1 && ct % 16 == 0) || (op.stride == 2 && ct % 8 == 0))) {
+            op.split_ok = true;        // stride 1: [chunk16][tap 9][Cout][32 halves]; stride 2: [chunk8][k-step 5][Cout][32 halves]
+            const size_t recs = op.stride == 1 ? (size_t)(ct / 16) * 9 : (size_t)(ct / 8) * 5;
+            op.dev_wh = wo; wo = align_up(wo + recs * op.cout * 16, 64);
+            op.dev_ws = wo; wo = align_up(wo + 1, 64);                  // 1 / scale, read by the kernel
+        }
     }
     e->weight_floats = wo;
     return TS2D_OK;
 }
 
+// fp32 -> fp16 bits, round to nearest even (host side of the weight split; the device uses v_cvt_f16_f32, also RNE)
+uint16_t f32_to_f16(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                       // rounds to >= 65520 -> inf
+    if (x < 0x38800000u) {                                                          // subnormal half (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int shift = 126 - (int)(x >> 23);                                     // 14..24
+        uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+        const uint32_t half = m >> shift, rem = m & ((1u << shift) - 1), mid = 1u << (shift - 1);
+        return (uint16_t)(sign | (half + ((rem > mid || (rem == mid && (half & 1))) ? 1 : 0)));
+    }
+    const uint32_t rem = x & 0x1FFFu;
+    uint32_t hbits = (x - 0x38000000u) >> 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (hbits & 1))) ++hbits;
+    return (uint16_t)(sign | hbits);
+}
+float f16_to_f32(uint16_t hb) {
+    const uint32_t sign = (uint32_t)(hb & 0x8000u) << 16, ex = (hb >> 10) & 0x1F, m = hb & 0x3FFu;
+    uint32_t x;
+    if (ex == 0) {
+        if (m == 0) x = sign;
+        else { float v = (float)m * 5.9604644775390625e-08f; memcpy(&x, &v, 4); x |= sign; }
+    } else if (ex == 31) x = sign | 0x7F800000u | (m << 13);
+    else x = sign | ((ex + 112) << 23) | (m << 13);
+    float f; memcpy(&f, &x, 4); return f;
+}
+
 // PyTorch-layout blob -> packed device layouts (host staging buffer `out`, weight_floats long).
 void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
     memset(out, 0, e->weight_floats * sizeof(float));
+    for (const Op& op : e->ops) {
+        if (op.type == OP_CONV && op.split_ok) {
+            // split-fp16 image: w * S = hi + lo with S = 2^k chosen so that max|w| * S is in [8192, 16384): hi and lo of
+            // typical weights stay in fp16's normal range, products stay far from fp32 overflow.
+            const int ct = op.cin + op.cin_skip, co_n = op.cout;
+            const float* w = blob + op.blob_w;
+            float mx = 0.f;
+            for (size_t i = 0; i < (size_t)co_n * ct * 9; ++i) mx = std::max(mx, std::fabs(w[i]));
+            const float wscale = (mx > 0.f && std::isfinite(mx)) ? std::exp2(std::floor(std::log2(16383.0f / mx))) : 1.f;
+            out[op.dev_ws] = 1.0f / wscale;
+            uint16_t* d = reinterpret_cast<uint16_t*>(out + op.dev_wh);
+            for (int co = 0; co < co_n; ++co)
+                for (int ci = 0; ci < ct; ++ci) {
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const float v = w[((size_t)co * ct + ci) * 9 + tap] * wscale;
+                        const uint16_t hi = f32_to_f16(v);
+                        const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
+                        if (op.stride == 1) {
+                            const int chunk = ci / 16, cc = ci % 16;
+                            uint16_t* rec = d + (((size_t)chunk * 9 + tap) * co_n + co) * 32;
+                            rec[cc] = hi; rec[16 + cc] = lo;
+                        } else {       // K packed as 8 channels x 2 taps: k = 8 * (tap & 1) + (ci % 8) of k-step tap / 2
+                            const int chunk = ci / 8, cc = (tap & 1) * 8 + ci % 8;
+                            uint16_t* rec = d + (((size_t)chunk * 5 + tap / 2) * co_n + co) * 32;
+                            rec[cc] = hi; rec[16 + cc] = lo;
+                        }
+                    }
+                }
+        }
+    }
     for (const Op& op : e->ops) {
         const int ct = op.cin + op.cin_skip, co_n = op.cout;
         if (op.type == OP_CONV) {           // W[co][ci][ky][kx] -> [chunk][tap][kk][co][8]
@@ -205,6 +277,7 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
 }
 
 int upload_weights(ts2d_engine* e, const float* blob, size_t n_floats) {
+    // (pack_weights also records the per-layer split scale in the op table)
     if (n_floats != e->blob_floats)
         return fail(TS2D_ERR_INVALID, "weight blob has %zu floats, architecture needs %zu", n_floats, e->blob_floats);
     std::vector<float> staging;
@@ -255,6 +328,48 @@ hipError_t launch_conv(int taps, int stride, int ck, int bn, const ConvArgs& a, 
     if (taps == 9 && stride == 2 && ck == 8 && bn == 64) return launch_conv_inst<9, 2, 8, 64, 0>(a, grid, smem, st);
     if (taps == 1 && stride == 1 && ck == 16 && bn == 32) return launch_conv_inst<1, 1, 16, 32, 1>(a, grid, smem, st);
     if (taps == 1 && stride == 1 && ck == 16 && bn == 64) return launch_conv_inst<1, 1, 16, 64, 1>(a, grid, smem, st);
+    return hipErrorInvalidConfiguration;
+}
+
+template <int BN, int MAXU>
+hipError_t launch_split_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv3x3_f16x3<BN, MAXU>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), smem, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_split(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    if (bn == 32 && maxu == 3) return launch_split_inst<32, 3>(a, grid, smem, st);
+    if (bn == 32 && maxu == 5) return launch_split_inst<32, 5>(a, grid, smem, st);
+    if (bn == 64 && maxu == 3) return launch_split_inst<64, 3>(a, grid, smem, st);
+    if (bn == 64 && maxu == 5) return launch_split_inst<64, 5>(a, grid, smem, st);
+    return hipErrorInvalidConfiguration;
+}
+
+template <int BN, int MAXU>
+hipError_t launch_split_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv3x3s2_f16x3<BN, MAXU>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), smem, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_s2(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    if (bn == 32 && maxu == 5) return launch_split_s2_inst<32, 5>(a, grid, smem, st);
+    if (bn == 32 && maxu == 6) return launch_split_s2_inst<32, 6>(a, grid, smem, st);
+    if (bn == 64 && maxu == 5) return launch_split_s2_inst<64, 5>(a, grid, smem, st);
+    if (bn == 64 && maxu == 6) return launch_split_s2_inst<64, 6>(a, grid, smem, st);
     return hipErrorInvalidConfiguration;
 }
 
@@ -358,20 +473,27 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             const int bn = (ca.N % 64 == 0 && op.cout % 64 == 0) ? 64 : 32;
             ca.n_mtiles = g.n_mtiles; ca.n_ctiles = ca.N / bn; ca.PH = g.PH; ca.PW = g.PW; ca.slope = a.leaky_slope;
             const int P = (g.PH * g.PW) << g.lgNIMG;
-            const size_t smem = std::max((size_t)(((P * (op.ck + 4) + 3) & ~3) + taps * (op.ck / 8) * bn * 8) * sizeof(float),
-                                         (size_t)4 * bn * 2 * sizeof(float));
+            const bool split = conv && op.split_ok && e->precision == TS2D_PRECISION_F32_SPLIT_F16X3;
+            size_t smem = std::max((size_t)(((P * (op.ck + 4) + 3) & ~3) + taps * (op.ck / 8) * bn * 8) * sizeof(float),
+                                   (size_t)4 * bn * 2 * sizeof(float));
+            if (split) {
+                smem = stride == 1 ? (size_t)P * kRec + (size_t)9 * bn * kRec : (size_t)P * kRec8 + (size_t)5 * bn * kRec;
+                smem = std::max(smem, (size_t)4 * bn * 2 * sizeof(float));
+                ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
+            }
             if (smem > 160 * 1024) return fail(TS2D_ERR_INVALID, "op %s: LDS tile of %zu bytes exceeds 160 KiB", op.name.c_str(), smem);
             const int grid = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
             TRY(prof_begin(e, op.name, st));
-            hipError_t le = launch_conv(taps, stride, op.ck, bn, ca, grid, smem, st);
+            hipError_t le = split ? (stride == 1 ? launch_split(bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, grid, smem, st)
+                                                 : launch_split_s2(bn, P <= 5 * kBlock ? 5 : 6, ca, grid, smem, st))
+                                  : launch_conv(taps, stride, op.ck, bn, ca, grid, smem, st);
             if (le != hipSuccess) return fail(TS2D_ERR_HIP, "launch of %s failed: %s", op.name.c_str(), hipGetErrorString(le));
             TRY(prof_end(e, st));
             if (conv) {
                 const int HW = Ht * Wt;
                 TRY(prof_begin(e, op.name + ".stats", st));
                 if (fused) {
-                    const int n = B * op.cout;
-                    hipLaunchKernelGGL(finalize_stats, dim3((n + 63) / 64), dim3(64), 0, st, e->d_part, g.tiles_x * g.tiles_y,
+                    hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
                                        op.cout, B, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 } else {
                     hipLaunchKernelGGL(stats_direct, dim3(B, op.cout / 32), dim3(256), 0, st, dst.data, op.cout, HW,
@@ -450,6 +572,14 @@ int ts2d_engine_load_weights(ts2d_engine* e, const float* weights, size_t n_floa
 int ts2d_engine_weight_buffer(ts2d_engine* e, void** dev_ptr, size_t* n_bytes) {
     if (!e || !dev_ptr || !n_bytes) return fail(TS2D_ERR_INVALID, "ts2d_engine_weight_buffer: null argument");
     *dev_ptr = e->d_weights; *n_bytes = e->weight_floats * sizeof(float);
+    return TS2D_OK;
+}
+
+int ts2d_engine_set_precision(ts2d_engine* e, int mode) {
+    if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_precision: null engine");
+    if (mode != TS2D_PRECISION_F32_EXACT && mode != TS2D_PRECISION_F32_SPLIT_F16X3)
+        return fail(TS2D_ERR_INVALID, "unknown precision mode %d", mode);
+    e->precision = mode;
     return TS2D_OK;
 }
 

@@ -39,6 +39,9 @@ struct ConvArgs {
     int n_mtiles, n_ctiles;
     int PH, PW;           // staged patch dims per image
     float slope;
+    const void* wph;      // split-fp16 packed weights [chunk][tap][N][16 hi | 16 lo] (f16x3 kernel only)
+    const float* oscale;  // device scalar: 1 / (power-of-two weight pre-scale); lives in the weight arena so that it
+                          // travels with the multi-GPU weight broadcast (f16x3 kernel only)
 };
 
 template <int STRIDE, int CK>
@@ -266,22 +269,27 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
 // biased variance, eps inside the sqrt, combined in double.
 // ------------------------------------------------------------------------------------------------------------
 // (a) from the conv epilogue's per-tile partial (sum, sum of squares): one thread per (n, c).
-__global__ void finalize_stats(const float* __restrict__ part, int ntiles, int C, int B, int HW,
-                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                               float* __restrict__ scale, float* __restrict__ shift) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * C) return;
-    const int n = idx / C, c = idx - n * C;
-    const float* p = part + ((size_t)n * ntiles * C + c) * 2;
+// Grid (B, C/32), 256 threads = 8 tile lanes x 32 channels; fixed summation order -> bit-reproducible.
+__global__ __launch_bounds__(256) void finalize_stats(const float* __restrict__ part, int ntiles, int C, int B, int HW,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    const int n = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, tl = threadIdx.x >> 5;
+    __shared__ double rs[8][32], rq[8][32];
+    const float2* p = reinterpret_cast<const float2*>(part) + (size_t)n * ntiles * C + c;
     double s = 0.0, q = 0.0;
-    for (int t = 0; t < ntiles; ++t) { s += (double)p[(size_t)t * C * 2]; q += (double)p[(size_t)t * C * 2 + 1]; }
-    const double mean = s / HW;
-    double var = q / HW - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    const double g = gamma[c];
-    scale[idx] = (float)(g * rstd);
-    shift[idx] = (float)((double)beta[c] - mean * g * rstd);
+    for (int t = tl; t < ntiles; t += 8) { const float2 v = p[(size_t)t * C]; s += (double)v.x; q += (double)v.y; }
+    rs[tl][cl] = s; rq[tl][cl] = q;
+    __syncthreads();
+    if (tl == 0) {
+        for (int k = 1; k < 8; ++k) { s += rs[k][cl]; q += rq[k][cl]; }
+        const double mean = s / HW;
+        double var = q / HW - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double g = gamma[c];
+        scale[(size_t)n * C + c] = (float)(g * rstd);
+        shift[(size_t)n * C + c] = (float)((double)beta[c] - mean * g * rstd);
+    }
 }
 
 // (b) directly from the raw NHWC tensor (small layers whose tile spans several images): block per (n, 32 channels).

@@ -82,6 +82,11 @@ class Engine:
     def weights_ready(self):
         _lib.check(self.lib.ts2d_engine_weights_ready(self._h), 'ts2d_engine_weights_ready')
 
+    def set_precision(self, mode):
+        """'exact' (fp32 MFMA) or 'split' (fp16 hi/lo x3 MFMA, fp32-equivalent accuracy; the default)."""
+        m = {'exact': _lib.PRECISION_F32_EXACT, 'split': _lib.PRECISION_F32_SPLIT_F16X3}.get(mode, mode)
+        _lib.check(self.lib.ts2d_engine_set_precision(self._h, int(m)), 'ts2d_engine_set_precision')
+
     # ------------------------------------------------------------------ forward
     def reserve(self, B: int, H: int, W: int):
         _lib.check(self.lib.ts2d_engine_reserve(self._h, B, H, W), 'ts2d_engine_reserve')
