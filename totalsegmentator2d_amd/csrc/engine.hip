@@ -4,10 +4,13 @@
 #include "../../include/ts2d_engine.h"
 #include "kernels.h"
 #include "kernels_f16x3.h"
+#include "kernels_f16x3_ws.h"
+#include "kernels_f16x3_convt.h"
 
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -73,6 +76,9 @@ struct ts2d_engine {
     float* d_weights = nullptr; size_t weight_floats = 0;
     bool weights_ready = false;
     int precision = TS2D_PRECISION_F32_SPLIT_F16X3;
+    bool use_ws = false;          // warp-specialised persistent split kernel: opt-in experiment (TS2D_WS=1); measured
+                                  // slower than two independent 256-thread workgroups per CU in round 1
+    int num_cus = 256;
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
     float* d_part = nullptr;
@@ -177,6 +183,11 @@ int build_program(ts2d_engine* e) {
             op.dev_wh = wo; wo = align_up(wo + recs * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);                  // 1 / scale, read by the kernel
         }
+        if (op.type == OP_CONVT && ct % 32 == 0) {                      // [chunk32][k-step 2][4*Cout][32 halves]
+            op.split_ok = true;
+            op.dev_wh = wo; wo = align_up(wo + (size_t)(ct / 32) * 2 * 4 * op.cout * 16, 64);
+            op.dev_ws = wo; wo = align_up(wo + 1, 64);
+        }
     }
     e->weight_floats = wo;
     return TS2D_OK;
@@ -216,6 +227,26 @@ float f16_to_f32(uint16_t hb) {
 void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
     memset(out, 0, e->weight_floats * sizeof(float));
     for (const Op& op : e->ops) {
+        if (op.type == OP_CONVT && op.split_ok) {
+            const int ct = op.cin, co_n = op.cout, N = 4 * co_n;
+            const float* w = blob + op.blob_w;
+            float mx = 0.f;
+            for (size_t i = 0; i < (size_t)ct * co_n * 4; ++i) mx = std::max(mx, std::fabs(w[i]));
+            const float wscale = (mx > 0.f && std::isfinite(mx)) ? std::exp2(std::floor(std::log2(16383.0f / mx))) : 1.f;
+            out[op.dev_ws] = 1.0f / wscale;
+            uint16_t* d = reinterpret_cast<uint16_t*>(out + op.dev_wh);
+            for (int ci = 0; ci < ct; ++ci) {
+                const int chunk = ci / 32, kk = (ci % 32) / 16, cc = ci % 16;
+                for (int co = 0; co < co_n; ++co)
+                    for (int ab = 0; ab < 4; ++ab) {
+                        const float v = w[((size_t)ci * co_n + co) * 4 + ab] * wscale;
+                        const uint16_t hi = f32_to_f16(v);
+                        const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
+                        uint16_t* rec = d + (((size_t)chunk * 2 + kk) * N + ab * co_n + co) * 32;
+                        rec[cc] = hi; rec[16 + cc] = lo;
+                    }
+            }
+        }
         if (op.type == OP_CONV && op.split_ok) {
             // split-fp16 image: w * S = hi + lo with S = 2^k chosen so that max|w| * S is in [8192, 16384): hi and lo of
             // typical weights stay in fp16's normal range, products stay far from fp32 overflow.
@@ -365,6 +396,25 @@ hipError_t launch_split_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStr
     return hipGetLastError();
 }
 
+template <int BN>
+hipError_t launch_split_ws_inst(const ConvArgs& a, int n_virtual, int grid, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv3x3_f16x3_ws<BN>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWsThreads), smem, st, a, n_virtual);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_ws(int bn, const ConvArgs& a, int n_virtual, int grid, size_t smem, hipStream_t st) {
+    if (bn == 32) return launch_split_ws_inst<32>(a, n_virtual, grid, smem, st);
+    if (bn == 64) return launch_split_ws_inst<64>(a, n_virtual, grid, smem, st);
+    return hipErrorInvalidConfiguration;
+}
+
 hipError_t launch_split_s2(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
     if (bn == 32 && maxu == 5) return launch_split_s2_inst<32, 5>(a, grid, smem, st);
     if (bn == 32 && maxu == 6) return launch_split_s2_inst<32, 6>(a, grid, smem, st);
@@ -473,7 +523,19 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             const int bn = (ca.N % 64 == 0 && op.cout % 64 == 0) ? 64 : 32;
             ca.n_mtiles = g.n_mtiles; ca.n_ctiles = ca.N / bn; ca.PH = g.PH; ca.PW = g.PW; ca.slope = a.leaky_slope;
             const int P = (g.PH * g.PW) << g.lgNIMG;
-            const bool split = conv && op.split_ok && e->precision == TS2D_PRECISION_F32_SPLIT_F16X3;
+            const bool split = op.split_ok && e->precision == TS2D_PRECISION_F32_SPLIT_F16X3;
+            if (split && !conv) {
+                ca.n_ctiles = ca.N / 64;                       // N = 4 * Cout is a multiple of 128; each 32-column tile lies in one (a,b) tap
+                ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
+                const int Pt = 1 << (g.lgTH + g.lgTW + g.lgNIMG);
+                const size_t smem_t = (size_t)2 * Pt * kRec + (size_t)2 * 64 * kRec;
+                const int grid_t = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
+                TRY(prof_begin(e, op.name, st));
+                hipLaunchKernelGGL(convT2x2_f16x3<64>, dim3(grid_t), dim3(kBlock), smem_t, st, ca);
+                HIP_TRY(hipGetLastError());
+                TRY(prof_end(e, st));
+                continue;
+            }
             size_t smem = std::max((size_t)(((P * (op.ck + 4) + 3) & ~3) + taps * (op.ck / 8) * bn * 8) * sizeof(float),
                                    (size_t)4 * bn * 2 * sizeof(float));
             if (split) {
@@ -484,9 +546,18 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             if (smem > 160 * 1024) return fail(TS2D_ERR_INVALID, "op %s: LDS tile of %zu bytes exceeds 160 KiB", op.name.c_str(), smem);
             const int grid = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
             TRY(prof_begin(e, op.name, st));
-            hipError_t le = split ? (stride == 1 ? launch_split(bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, grid, smem, st)
-                                                 : launch_split_s2(bn, P <= 5 * kBlock ? 5 : 6, ca, grid, smem, st))
-                                  : launch_conv(taps, stride, op.ck, bn, ca, grid, smem, st);
+            // warp-specialised persistent kernel: stride 1, tile inside one image, patch <= 384 pixels
+            const bool ws = split && stride == 1 && g.lgNIMG == 0 && P <= 384 && e->use_ws;
+            hipError_t le;
+            if (ws) {
+                const size_t smem_ws = 2 * ((size_t)P * kRec + (size_t)9 * bn * kRec) + (size_t)4 * bn * 2 * sizeof(float);
+                le = launch_split_ws(bn, ca, grid, std::min(grid, e->num_cus), smem_ws, st);
+            } else if (split) {
+                le = stride == 1 ? launch_split(bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, grid, smem, st)
+                                 : launch_split_s2(bn, P <= 5 * kBlock ? 5 : 6, ca, grid, smem, st);
+            } else {
+                le = launch_conv(taps, stride, op.ck, bn, ca, grid, smem, st);
+            }
             if (le != hipSuccess) return fail(TS2D_ERR_HIP, "launch of %s failed: %s", op.name.c_str(), hipGetErrorString(le));
             TRY(prof_end(e, st));
             if (conv) {
@@ -544,6 +615,12 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
     ts2d_engine* e = new (std::nothrow) ts2d_engine();
     if (!e) return fail(TS2D_ERR_NOMEM, "host allocation failed");
     e->arch = *arch; e->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
+        const char* ws = getenv("TS2D_WS");
+        e->use_ws = ws && ws[0] == '1';
+    }
     int rc = build_program(e);
     if (rc != TS2D_OK) { delete e; return rc; }
     hipError_t he = hipSetDevice(device);

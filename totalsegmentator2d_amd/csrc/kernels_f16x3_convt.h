@@ -1,0 +1,183 @@
+// Split-fp16 ConvTranspose2d 2x2 stride 2: a GEMM with M = input pixels, N = 4 * Cout ((a,b) tap-major),
+// K = Cin, on v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi like kernels_f16x3.h).  No halo; chunks of 32 input
+// channels; the epilogue scatters column n = (2a+b) * Cout + co of input pixel (y, x) to output pixel (2y+a, 2x+b).
+// HBM-bound at high resolution (writes 4x the pixels it reads); the point of the split MFMA here is to take the
+// arithmetic (8x64-cycle fp32 MFMAs per 32x32x16 block) off the critical path.
+#pragma once
+#include "kernels_f16x3.h"
+
+namespace ts2d {
+
+template <int BN>
+__global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
+    constexpr int NT = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = bid >> 3;
+    const int mtile = (q8 / a.n_ctiles) * 8 + xcd;
+    const int ctile = q8 % a.n_ctiles;
+    if (mtile >= a.n_mtiles) return;
+    const int n0col = ctile * BN;
+
+    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW, NIMG = 1 << a.lgNIMG;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int grp = mtile / tpi, tin = mtile - grp * tpi;
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
+    const int nimg0 = grp << a.lgNIMG;
+    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int P = (TH * TW) << a.lgNIMG;              // <= 256 tile pixels, no halo
+    unsigned char* sA = smem8;                        // [kk 2][P][80 B]
+    unsigned char* sB = smem8 + 2 * P * kRec;         // [kk 2][BN][80 B]
+
+    // staging unit u = (pixel u >> 2, channel octet u & 3): 4 units per thread, pixel = tile row m
+    int goff[4], nimg[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int u = tid + it * kBlock;
+        const int m = u >> 2;
+        int g = -1, n = 0;
+        if (m < P) {
+            const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+            n = nimg0 + il;
+            const int iy = ty0 + ty, ix = tx0 + tx;
+            if (il < NIMG && n < a.B && iy < a.Hin && ix < a.Win) g = (n * a.Hin + iy) * a.Win + ix;
+        }
+        goff[it] = g; nimg[it] = n;
+    }
+    const int oct = (tid & 3) * 8;                    // kBlock % 4 == 0: the octet is the same for all 4 units
+
+    int abase[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) abase[mt] = (64 * w + 32 * mt + r) * kRec + 16 * h;      // record = tile row m
+    const int bbase = r * kRec + 16 * h;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    const int nchunks = a.C0 / 32;
+    f32x4 pv[4][2];
+    auto prefetch = [&](int ch) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            pv[it][0] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (goff[it] >= 0) {
+                const float* p = a.src0 + (size_t)goff[it] * a.C0 + ch * 32 + oct;
+                pv[it][0] = *reinterpret_cast<const f32x4*>(p);
+                pv[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            }
+        }
+    };
+
+    prefetch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int u = tid + it * kBlock;
+            const int m = u >> 2;
+            if (m < P) {
+                f32x4 va = pv[it][0], vb = pv[it][1];
+                if (a.sc0 != nullptr && goff[it] >= 0) {
+                    const size_t o = (size_t)nimg[it] * a.C0 + ch * 32 + oct;
+                    const f32x4 s1a = *reinterpret_cast<const f32x4*>(a.sc0 + o), s1b = *reinterpret_cast<const f32x4*>(a.sc0 + o + 4);
+                    const f32x4 s2a = *reinterpret_cast<const f32x4*>(a.sh0 + o), s2b = *reinterpret_cast<const f32x4*>(a.sh0 + o + 4);
+                    va = va * s1a + s2a; vb = vb * s1b + s2b;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        va[e] = fmaxf(va[e], va[e] * a.slope);
+                        vb[e] = fmaxf(vb[e], vb[e] * a.slope);
+                    }
+                }
+                half8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 ha = (_Float16)va[e], hb = (_Float16)vb[e];
+                    hi[e] = ha; hi[e + 4] = hb;
+                    lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb);
+                }
+                // octet o8 = u & 3: k-step kk = o8 >> 1, half of the 16-channel record = o8 & 1
+                unsigned char* d = sA + (((u & 3) >> 1) * P + m) * kRec + (u & 1) * 16;
+                *reinterpret_cast<half8*>(d) = hi;
+                *reinterpret_cast<half8*>(d + 32) = lo;
+            }
+        }
+        {
+            constexpr int WU = 2 * BN * 4;
+            const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * 2 * a.N + n0col) * 4;
+#pragma unroll
+            for (int it = 0; it < (WU + kBlock - 1) / kBlock; ++it) {
+                const int idx = tid + it * kBlock;
+                if (idx < WU) {
+                    const int tc = idx >> 2, part = idx & 3;
+                    const int kk = tc / BN, col = tc - kk * BN;
+                    *reinterpret_cast<uint4*>(sB + tc * kRec + part * 16) = wsrc[((size_t)kk * a.N + col) * 4 + part];
+                }
+            }
+        }
+        __syncthreads();
+        if (ch + 1 < nchunks) prefetch(ch + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                ah[mt] = *reinterpret_cast<const half8*>(sA + kk * P * kRec + abase[mt]);
+                al[mt] = *reinterpret_cast<const half8*>(sA + kk * P * kRec + abase[mt] + 32);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bh[nt] = *reinterpret_cast<const half8*>(sB + (kk * BN + nt * 32) * kRec + bbase);
+                bl[nt] = *reinterpret_cast<const half8*>(sB + (kk * BN + nt * 32) * kRec + bbase + 32);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    const float oscale = *a.oscale;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ab = (n0col + nt * 32) / a.Cout;
+        const int co = n0col + nt * 32 - ab * a.Cout + r;
+        const int oa = ab >> 1, ob = ab & 1;
+        const float bv = a.bias[co];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int m = 64 * w + 32 * mt + row;
+                const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+                const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
+                if (il < NIMG && n < a.B && oy < a.Ht && ox < a.Wt)
+                    a.dst[((size_t)(n * 2 * a.Ht + 2 * oy + oa) * (2 * a.Wt) + 2 * ox + ob) * a.Cout + co] =
+                        acc[mt][nt][i] * oscale + bv;
+            }
+        }
+    }
+}
+
+}  // namespace ts2d
