@@ -25,6 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak (same guide); the split path issues 3 fp16 MFMA products per MAC
 PEAK_HBM_GBS = 8000.0
 
 
@@ -41,15 +42,21 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get('TS2D_CPU_THREADS', 16))))
 
 
-def cpu_baseline(arch, sd, budget_s: float = 20.0):
+def cpu_baseline(arch, sd, budget_s: float = 20.0, check=None):
     """The oracle (torch-CPU restatement = the ATen kernels the reference CPU path runs), B = 1 per call like the
-    reference, all host cores, on a bounded sample of the same workload."""
+    reference, all host cores, on a bounded sample of the same workload.  `check` = (x, gpu logits)
+    of one slice: the oracle's output on it gives the live logit max-abs-err of the metric."""
     import torch
     from oracle import torch_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
     x = torch.randn(1, arch.input_channels, 512, 512)
-    O.unet_forward(arch, sd, x)                      # warm-up
+    err = None
+    if check is not None:
+        ref = O.unet_forward(arch, sd, check[0]).numpy()         # doubles as the warm-up
+        err = float(np.abs(ref - check[1]).max())
+    else:
+        O.unet_forward(arch, sd, x)                  # warm-up
     t0 = time.time()
     n = 0
     while n < 3 or (time.time() - t0 < budget_s and n < 64):
@@ -58,7 +65,7 @@ def cpu_baseline(arch, sd, budget_s: float = 20.0):
     dt = time.time() - t0
     return {'value': round(n / dt, 3), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} single-slice (B=1, no mirroring) 2x512x512 forwards of the same network, torch-CPU oracle, '
-                      f'{torch.get_num_threads()} threads'}
+                      f'{torch.get_num_threads()} threads'}, err
 
 
 def main():
@@ -69,6 +76,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='slices per GPU per step (config 2: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
+    ap.add_argument('--precision', choices=('split', 'exact'), default='split',
+                    help="split: fp16 hi/lo x3 MFMA with fp32 accumulation (fp32-equivalent accuracy, default); exact: fp32 MFMA")
     args = ap.parse_args()
 
     import torch
@@ -106,6 +115,7 @@ def main():
     logits = torch.empty(B, arch.num_classes, H, W, device=dev)
     mask = torch.empty(B, arch.num_classes, H, W // 32, dtype=torch.int32, device=dev)
     engine.reserve(B, H, W)
+    engine.set_precision(args.precision)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
@@ -150,29 +160,56 @@ def main():
         }
         if bcast_ms is not None:
             out['weight_broadcast_ms'] = round(bcast_ms, 2)
+        split = args.precision == 'split'
+        out['dtype'] = 'f32 storage/accumulate, products as 3x fp16-split MFMA (f16x3)' if split else 'f32'
+        out['precision_mode'] = args.precision
         if profile and op_ms:
-            # dominant kernel = the implicit-GEMM conv (conv_mfma_f32, TAPS=9): all 30 Conv2d 3x3 launches of a step
-            per = {o['name']: 2.0 * m['macs'] for o, m in zip(arch.program(), work['per_layer']) if o['op'] == OP_CONV3X3}
+            # dominant kernel = the stride-1 3x3 implicit-GEMM conv (conv3x3_f16x3 / conv_mfma_f32<9,1,..>): 22 launches/step
+            prog = arch.program()
+            per = {o['name']: 2.0 * m['macs'] for o, m in zip(prog, work['per_layer'])
+                   if o['op'] == OP_CONV3X3 and o['stride'] == 1 and o['src'] != 'input'}
             conv_ms = sum(v for k, v in op_ms.items() if k in per) / args.steps
             conv_flops = sum(per.values()) * B
             achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+            peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
             traffic = None
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get('conv_mfma_f32_hbm_bytes_per_step')
+                    traffic = json.load(open(pmc)).get(f'conv3x3_s1_{args.precision}_hbm_bytes_per_launch_avg')
                 except Exception:
                     traffic = None
-            out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
-                               'kernel': 'conv_mfma_f32<TAPS=9> (30 launches/step)',
-                               'kernel_ms_per_step': round(conv_ms, 3),
-                               'kernel_share_of_step': round(conv_ms / ms_per_step, 4),
-                               'whole_step_hbm_frac_layerwise': round(value / world * work['act_bytes'] / 1e9 / PEAK_HBM_GBS, 4)}
+            all3 = {o['name'] for o in prog if o['op'] == OP_CONV3X3}
+            out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                               'frac': round(achieved / peak, 4), 'traffic': traffic,
+                               'kernel': ('conv3x3_f16x3' if split else 'conv_mfma_f32<9,1,16,*>') + f' ({len(per)} launches/step)',
+                               'peak_note': ('dense fp16 MFMA 2500 TFLOP/s / 3 products per MAC' if split else 'fp32 MFMA 32x32x2'),
+                               'algorithmic_flop_per_launch_avg': round(conv_flops / len(per)),
+                               'kernel_ms_per_launch_avg': round(conv_ms / len(per), 4),
+                               'kernel_ms_per_step': round(conv_ms, 3), 'kernel_share_of_step': round(conv_ms / ms_per_step, 4),
+                               'all_conv3x3_ms_per_step': round(sum(v for k, v in op_ms.items() if k in all3) / args.steps, 3),
+                               'whole_step_hbm_frac_layerwise': round(value / world * work['act_bytes'] / 1e9 / PEAK_HBM_GBS, 4),
+                               'whole_step_fp32_mfma_equiv_frac': round(value / world * work['flops'] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
             top = sorted(op_ms.items(), key=lambda kv: -kv[1])[:8]
             out['top_ops_ms'] = {k: round(v / args.steps, 3) for k, v in top}
+        if world == 1:
+            # the other arithmetic mode on the same workload (outside the timed region above; same step definition)
+            other = 'exact' if split else 'split'
+            engine.set_profiling(False)
+            engine.set_precision(other)
+            step(); torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(max(2, args.steps // 2)):
+                step()
+            torch.cuda.synchronize(dev)
+            out['other_mode'] = {'precision_mode': other, 'value': round(B * max(2, args.steps // 2) / (time.perf_counter() - t1), 2), 'unit': 'slices/s'}
+            engine.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(arch, sd)
+            step(); torch.cuda.synchronize(dev)
+            chk = (x[:1].cpu().numpy(), logits[:1].cpu().numpy())
+            out['cpu_baseline'], err = cpu_baseline(arch, sd, check=chk)
+            out['logit_max_abs_err_vs_oracle'] = {'value': err, 'tol': 1e-4, 'slices_checked': 1,
+                                                  'note': 'live check in the cpu_baseline leg; full parity: pytest -m gpu'}
         print(json.dumps(out), flush=True)
     engine.close()
     if multi:

@@ -6,6 +6,7 @@
 #include "kernels_f16x3.h"
 #include "kernels_f16x3_ws.h"
 #include "kernels_f16x3_convt.h"
+#include "kernels_f16x3_pp.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -79,6 +80,8 @@ struct ts2d_engine {
     bool use_ws = false;          // warp-specialised persistent split kernel: opt-in experiment (TS2D_WS=1); measured
                                   // slower than two independent 256-thread workgroups per CU in round 1
     int num_cus = 256;
+    bool use_pp = false;          // ping-pong split kernel: opt-in experiment (TS2D_PP=1); measured slower in round 1
+    int stagger = 3;              // start offset between co-resident workgroups, units of ~1024 cycles (TS2D_STAGGER)
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
     float* d_part = nullptr;
@@ -362,10 +365,10 @@ hipError_t launch_conv(int taps, int stride, int ck, int bn, const ConvArgs& a, 
     return hipErrorInvalidConfiguration;
 }
 
-template <int BN, int MAXU>
+template <int BN, int MAXU, int PF = 1>
 hipError_t launch_split_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv3x3_f16x3<BN, MAXU>;
+    auto kern = conv3x3_f16x3<BN, MAXU, PF>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -376,7 +379,7 @@ hipError_t launch_split_inst(const ConvArgs& a, int grid, size_t smem, hipStream
 }
 
 hipError_t launch_split(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    if (bn == 32 && maxu == 3) return launch_split_inst<32, 3>(a, grid, smem, st);
+    if (bn == 32 && maxu == 3) return launch_split_inst<32, 3>(a, grid, smem, st);      // (PF = 2 measured slower: 2 instead of 3 workgroups/CU)
     if (bn == 32 && maxu == 5) return launch_split_inst<32, 5>(a, grid, smem, st);
     if (bn == 64 && maxu == 3) return launch_split_inst<64, 3>(a, grid, smem, st);
     if (bn == 64 && maxu == 5) return launch_split_inst<64, 5>(a, grid, smem, st);
@@ -412,6 +415,27 @@ hipError_t launch_split_ws_inst(const ConvArgs& a, int n_virtual, int grid, size
 hipError_t launch_split_ws(int bn, const ConvArgs& a, int n_virtual, int grid, size_t smem, hipStream_t st) {
     if (bn == 32) return launch_split_ws_inst<32>(a, n_virtual, grid, smem, st);
     if (bn == 64) return launch_split_ws_inst<64>(a, n_virtual, grid, smem, st);
+    return hipErrorInvalidConfiguration;
+}
+
+template <int BN, int MAXU>
+hipError_t launch_split_pp_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv3x3_f16x3_pp<BN, MAXU>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_pp(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    if (bn == 32 && maxu == 3) return launch_split_pp_inst<32, 3>(a, grid, smem, st);
+    if (bn == 32 && maxu == 5) return launch_split_pp_inst<32, 5>(a, grid, smem, st);
+    if (bn == 64 && maxu == 3) return launch_split_pp_inst<64, 3>(a, grid, smem, st);
+    if (bn == 64 && maxu == 5) return launch_split_pp_inst<64, 5>(a, grid, smem, st);
     return hipErrorInvalidConfiguration;
 }
 
@@ -542,6 +566,7 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 smem = stride == 1 ? (size_t)P * kRec + (size_t)9 * bn * kRec : (size_t)P * kRec8 + (size_t)5 * bn * kRec;
                 smem = std::max(smem, (size_t)4 * bn * 2 * sizeof(float));
                 ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
+                ca.stagger = e->stagger;
             }
             if (smem > 160 * 1024) return fail(TS2D_ERR_INVALID, "op %s: LDS tile of %zu bytes exceeds 160 KiB", op.name.c_str(), smem);
             const int grid = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
@@ -549,7 +574,12 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             // warp-specialised persistent kernel: stride 1, tile inside one image, patch <= 384 pixels
             const bool ws = split && stride == 1 && g.lgNIMG == 0 && P <= 384 && e->use_ws;
             hipError_t le;
-            if (ws) {
+            const size_t smem_pp = 2 * ((size_t)P * kRec + (size_t)9 * bn * kRec) + (size_t)2 * 4 * bn * 2 * sizeof(float);
+            const bool pp = split && stride == 1 && !ws && e->use_pp && smem_pp <= 160 * 1024;
+            if (pp) {      // ping-pong kernel: two pixel tiles per 512-thread workgroup in enforced anti-phase
+                const int n_pairs = (g.n_mtiles + 1) / 2;
+                le = launch_split_pp(bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, (n_pairs + 7) / 8 * 8 * ca.n_ctiles, smem_pp, st);
+            } else if (ws) {
                 const size_t smem_ws = 2 * ((size_t)P * kRec + (size_t)9 * bn * kRec) + (size_t)4 * bn * 2 * sizeof(float);
                 le = launch_split_ws(bn, ca, grid, std::min(grid, e->num_cus), smem_ws, st);
             } else if (split) {
@@ -618,6 +648,8 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
+        if (getenv("TS2D_STAGGER")) e->stagger = atoi(getenv("TS2D_STAGGER"));
+        if (getenv("TS2D_PP")) e->use_pp = getenv("TS2D_PP")[0] == '1';
         const char* ws = getenv("TS2D_WS");
         e->use_ws = ws && ws[0] == '1';
     }

@@ -40,6 +40,7 @@ struct ConvArgs {
     int PH, PW;           // staged patch dims per image
     float slope;
     const void* wph;      // split-fp16 packed weights [chunk][tap][N][16 hi | 16 lo] (f16x3 kernel only)
+    int stagger;          // first-round workgroups in SIMD wave slot k start k * stagger * ~1024 cycles late (0 = off)
     const float* oscale;  // device scalar: 1 / (power-of-two weight pre-scale); lives in the weight arena so that it
                           // travels with the multi-GPU weight broadcast (f16x3 kernel only)
 };

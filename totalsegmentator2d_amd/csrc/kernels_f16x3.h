@@ -20,6 +20,24 @@ constexpr int kRec = 80;
 
 // Shared epilogue: undo the weight pre-scale, add bias, store the raw NHWC output, per-tile InstanceNorm partials.
 // C/D map of the 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).
+
+// De-synchronise the workgroups that share a CU.  Identical workgroups dispatched together run in lockstep: their MFMA
+// phases collide and their staging phases collide, so nothing overlaps (measured: time = MFMA + staging).  Delaying the
+// workgroup that sits in SIMD wave slot k by k * stagger at kernel start makes one workgroup's MFMA phase coincide
+// with the other's staging phase, and equal-length workgroups keep that offset for the rest of the launch
+// (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Only first-round workgroups are delayed; later ones start
+// whenever a slot frees and inherit the offset.
+__device__ __forceinline__ void stagger_start(const ConvArgs& a, unsigned char* smem8) {
+    if (a.stagger > 0 && blockIdx.x < 1024) {
+        unsigned* flag = reinterpret_cast<unsigned*>(smem8);
+        if (threadIdx.x == 0) *flag = __builtin_amdgcn_s_getreg(6148) & 15u;     // HW_REG_HW_ID[3:0] = wave slot on its SIMD
+        __syncthreads();
+        const unsigned slot = *flag;
+        __syncthreads();
+        for (unsigned k = 0; k < slot * (unsigned)a.stagger; ++k) __builtin_amdgcn_s_sleep(16);
+    }
+}
+
 template <int BN>
 __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t)[2][BN / 32], unsigned char* smem8,
                                                int n0col, int nimg0, int ty0, int tx0, int tpi, int tin) {
@@ -70,7 +88,8 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
     }
 }
 
-template <int BN, int MAXU>
+// PF = chunks of raw patch data kept in flight in registers (2 for the HBM-bound small-Cin layers: more bytes in flight).
+template <int BN, int MAXU, int PF = 1>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
     constexpr int NT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
@@ -96,6 +115,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
     const int P = PHW << a.lgNIMG;
     unsigned char* sA = smem8;
     unsigned char* sB = smem8 + P * kRec;
+    stagger_start(a, smem8);
 
     // ---- staging plan: unit u = (patch pixel u >> 1, channel octet u & 1); divisions by float reciprocal (exact here)
     int goff[MAXU];
@@ -136,29 +156,33 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
             for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
 
     const int nchunks = (a.C0 + a.C1) / 16;
-    f32x4 pv[MAXU][2];                 // prefetched raw patch values of the NEXT chunk (in flight during the MFMAs)
+    f32x4 pv[PF][MAXU][2];             // prefetched raw patch values of the next PF chunks (in flight during the MFMAs)
 
     auto chunk_src = [&](int ch, const float*& src, const float*& sc, const float*& sh, int& C, int& cb) {
         cb = ch * 16;
         if (cb < a.C0) { src = a.src0; sc = a.sc0; sh = a.sh0; C = a.C0; }
         else { cb -= a.C0; src = a.src1; sc = a.sc1; sh = a.sh1; C = a.C1; }
     };
-    auto prefetch = [&](int ch) {
+    auto prefetch = [&](int ch, f32x4 (&pq)[MAXU][2]) {
         const float* src; const float* sc; const float* sh; int C, cb;
         chunk_src(ch, src, sc, sh, C, cb);
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
-            pv[it][0] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pq[it][0] = f32x4{0.f, 0.f, 0.f, 0.f}; pq[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (goff[it] >= 0) {
                 const float* p = src + (size_t)goff[it] * C + cb + oct;
-                pv[it][0] = *reinterpret_cast<const f32x4*>(p);
-                pv[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
+                pq[it][0] = *reinterpret_cast<const f32x4*>(p);
+                pq[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
             }
         }
     };
 
-    prefetch(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) prefetch(s, pv[s]);          // nchunks >= 2 and even (channels are multiples of 32)
+    for (int ch0 = 0; ch0 < nchunks; ch0 += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        const int ch = ch0 + s;
         const float* src; const float* sc; const float* sh; int C, cb;
         chunk_src(ch, src, sc, sh, C, cb);
         __syncthreads();   // the previous chunk's MFMA reads of LDS are done
@@ -174,7 +198,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
             for (int it = 0; it < MAXU; ++it) {
                 const int u = tid + it * kBlock;
                 if (u < total) {
-                    f32x4 va = pv[it][0], vb = pv[it][1];
+                    f32x4 va = pv[s][it][0], vb = pv[s][it][1];
                     if (sc != nullptr && goff[it] >= 0) {
                         if (a.lgNIMG != 0) {
                             const size_t o = (size_t)(nimg0 + (int)((imgbits >> (4 * it)) & 15)) * C + cb + oct;
@@ -216,7 +240,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
             }
         }
         __syncthreads();
-        if (ch + 1 < nchunks) prefetch(ch + 1);   // HBM latency hides behind the MFMA phase below
+        if (ch + PF < nchunks) prefetch(ch + PF, pv[s]);   // HBM latency hides behind the MFMA phases
 
         f32x16 acc_c[2][NT];
 #pragma unroll
@@ -225,6 +249,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc_c[mt][nt][i] = 0.f;
+        __builtin_amdgcn_s_setprio(1);     // the MFMA phase outranks the co-resident workgroup's staging phase
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = ((tap / 3) * a.PW + (tap % 3)) * kRec;
@@ -255,10 +280,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
                 for (int nt = 0; nt < NT; ++nt)
                     acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
+    }
     }
 
     split_epilogue<BN>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
@@ -299,6 +326,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
     const int P = PHW << a.lgNIMG;
     unsigned char* sA = smem8;
     unsigned char* sB = smem8 + P * kRec8;
+    stagger_start(a, smem8);
 
     int goff[MAXU], lrec[MAXU];
     unsigned long long imgbits = 0;
