@@ -7,6 +7,7 @@
 #include "kernels_f16x3_ws.h"
 #include "kernels_f16x3_convt.h"
 #include "kernels_f16x3_pp.h"
+#include "kernels_first.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -57,6 +58,8 @@ struct Op {
     bool split_ok = false;        // eligible for the split-fp16 kernel (3x3, stride 1, Cin % 16 == 0, not the net input)
     size_t dev_wh = 0;            // offset (floats) of the split-fp16 weights in the arena
     size_t dev_ws = 0;            // offset (floats) of 1 / (power-of-two pre-scale of the split weights)
+    bool first_direct = false;    // first conv block handled by conv3x3_first (reads the NCHW boundary tensor)
+    size_t dev_wraw = 0;
 };
 
 struct Launch { std::string name; hipEvent_t e0 = nullptr, e1 = nullptr; };
@@ -85,6 +88,7 @@ struct ts2d_engine {
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
     float* d_part = nullptr;
+    float* d_partial = nullptr;   // split-K partial outputs
     float* d_in_stage = nullptr; float* d_logit_stage = nullptr; uint32_t* d_mask_stage = nullptr;
     hipStream_t stream = nullptr;
     bool profiling = false;
@@ -186,6 +190,10 @@ int build_program(ts2d_engine* e) {
             op.dev_wh = wo; wo = align_up(wo + recs * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);                  // 1 / scale, read by the kernel
         }
+        if (op.type == OP_CONV && op.src == 0 && ct <= 4) {              // first block: PyTorch-layout fp32 copy for conv3x3_first
+            op.dev_wraw = wo; wo = align_up(wo + (size_t)op.cout * ct * 9, 64);
+            op.first_direct = true;
+        }
         if (op.type == OP_CONVT && ct % 32 == 0) {                      // [chunk32][k-step 2][4*Cout][32 halves]
             op.split_ok = true;
             op.dev_wh = wo; wo = align_up(wo + (size_t)(ct / 32) * 2 * 4 * op.cout * 16, 64);
@@ -230,6 +238,7 @@ float f16_to_f32(uint16_t hb) {
 void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
     memset(out, 0, e->weight_floats * sizeof(float));
     for (const Op& op : e->ops) {
+        if (op.first_direct) memcpy(out + op.dev_wraw, blob + op.blob_w, (size_t)op.cout * op.cin * 9 * sizeof(float));
         if (op.type == OP_CONVT && op.split_ok) {
             const int ct = op.cin, co_n = op.cout, N = 4 * co_n;
             const float* w = blob + op.blob_w;
@@ -374,7 +383,7 @@ hipError_t launch_split_inst(const ConvArgs& a, int grid, size_t smem, hipStream
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
 
@@ -395,7 +404,7 @@ hipError_t launch_split_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStr
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
 
@@ -447,6 +456,29 @@ hipError_t launch_split_s2(int bn, int maxu, const ConvArgs& a, int grid, size_t
     return hipErrorInvalidConfiguration;
 }
 
+// Split-K factor for a split-fp16 conv whose grid would leave most CUs idle (8x8 / 4x4 bottleneck levels).
+int choose_ksplit(const ts2d_engine* e, const Op& op, int B, int H, int W) {
+    if (op.type != OP_CONV || !op.split_ok || op.first_direct) return 1;
+    const TileGeom g = tile_geom(B, H >> op.level, W >> op.level, op.stride, 9);
+    // The factor depends on the layer geometry only (never on B), so a slice computes bit-identically alone or in a batch:
+    // tiles that hold >= 4 whole images (<= 8x8 pixels per image) leave most CUs idle -> split K as far as 4 chunks/slice.
+    (void)B;
+    if (g.lgNIMG < 2) return 1;
+    const int nchunks = (op.cin + op.cin_skip) / (op.stride == 1 ? 16 : 8);
+    int S = 1;
+    while (S < 8 && nchunks / (S * 2) >= 4) S *= 2;
+    return S;
+}
+
+size_t partial_floats_needed(const ts2d_engine* e, int B, int H, int W) {
+    size_t mx = 0;
+    for (const Op& op : e->ops) {
+        const int S = choose_ksplit(e, op, B, H, W);
+        if (S > 1) mx = std::max(mx, (size_t)S * B * (H >> op.level) * (W >> op.level) * op.cout);
+    }
+    return mx;
+}
+
 size_t part_floats_needed(const ts2d_engine* e, int B, int H, int W) {
     size_t mx = 0;
     for (const Op& op : e->ops) {
@@ -475,6 +507,7 @@ int ensure_workspace(ts2d_engine* e, int B, int H, int W) {
         }
     }
     const size_t o_part = off; off = align_up(off + part_floats_needed(e, B, H, W) * sizeof(float) + 256, 256);
+    const size_t o_pk = off; off = align_up(off + partial_floats_needed(e, B, H, W) * sizeof(float) + 256, 256);   // split-K partials
     const size_t o_in = off; off = align_up(off + (size_t)B * e->arch.input_channels * H * W * sizeof(float), 256);
     const size_t o_lg = off; off = align_up(off + (size_t)B * K * H * W * sizeof(float), 256);
     const size_t o_mk = off; off = align_up(off + (size_t)B * K * H * ((W + 31) / 32) * sizeof(uint32_t), 256);
@@ -487,6 +520,7 @@ int ensure_workspace(ts2d_engine* e, int B, int H, int W) {
         t.shift = t.normed ? reinterpret_cast<float*>(e->d_ws + o_sh[i]) : nullptr;
     }
     e->d_part = reinterpret_cast<float*>(e->d_ws + o_part);
+    e->d_partial = reinterpret_cast<float*>(e->d_ws + o_pk);
     e->d_in_stage = reinterpret_cast<float*>(e->d_ws + o_in);
     e->d_logit_stage = reinterpret_cast<float*>(e->d_ws + o_lg);
     e->d_mask_stage = reinterpret_cast<uint32_t*>(e->d_ws + o_mk);
@@ -517,7 +551,7 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
     const ts2d_arch_desc& a = e->arch;
     e->n_launched = 0;
     e->lastB = B; e->lastH = H; e->lastW = W; e->last_stream = st;
-    {   // boundary layout change NCHW -> NHWC (channels zero-padded to 8)
+    if (!e->ops[0].first_direct) {   // boundary layout change NCHW -> NHWC (channels zero-padded to 8); > 4 input channels only
         const long long total = (long long)B * H * W;
         TRY(prof_begin(e, "input.nhwc", st));
         hipLaunchKernelGGL(nchw_to_nhwc_pad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
@@ -528,6 +562,37 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
     for (const Op& op : e->ops) {
         const Tensor& src = e->tensors[op.src];
         const float* wts = e->d_weights;
+        if (op.first_direct) {
+            Tensor& dst = e->tensors[op.dst];
+            const TileGeom g = tile_geom(B, H, W, 1, 9);
+            FirstArgs fa{};
+            fa.x = d_in; fa.w = wts + op.dev_wraw; fa.bias = wts + op.dev_b; fa.dst = dst.data;
+            const bool fused = g.lgNIMG == 0;
+            fa.part = fused ? e->d_part : nullptr;
+            fa.B = B; fa.C = op.cin; fa.H = H; fa.W = W; fa.Cout = op.cout;
+            fa.lgTH = g.lgTH; fa.lgTW = g.lgTW; fa.lgNIMG = g.lgNIMG; fa.tiles_x = g.tiles_x; fa.tiles_y = g.tiles_y;
+            fa.n_mtiles = g.n_mtiles; fa.PH = g.PH; fa.PW = g.PW;
+            const int kp = (op.cin + 1) / 2, nt = op.cout / 32, P = (g.PH * g.PW) << g.lgNIMG;
+            const size_t smem = std::max((size_t)P * (2 * kp + 1) * sizeof(float), (size_t)4 * op.cout * 2 * sizeof(float));
+            TRY(prof_begin(e, op.name, st));
+            if (nt == 1 && kp == 1) hipLaunchKernelGGL((conv3x3_first<1, 1>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa);
+            else if (nt == 1 && kp == 2) hipLaunchKernelGGL((conv3x3_first<1, 2>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa);
+            else if (nt == 2 && kp == 1) hipLaunchKernelGGL((conv3x3_first<2, 1>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa);
+            else if (nt == 2 && kp == 2) hipLaunchKernelGGL((conv3x3_first<2, 2>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa);
+            else return fail(TS2D_ERR_INVALID, "first block: unsupported Cout %d / Cin %d", op.cout, op.cin);
+            HIP_TRY(hipGetLastError());
+            TRY(prof_end(e, st));
+            TRY(prof_begin(e, op.name + ".stats", st));
+            if (fused)
+                hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
+                                   op.cout, B, H * W, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+            else
+                hipLaunchKernelGGL(stats_direct, dim3(B, op.cout / 32), dim3(256), 0, st, dst.data, op.cout, H * W,
+                                   wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+            HIP_TRY(hipGetLastError());
+            TRY(prof_end(e, st));
+            continue;
+        }
         if (op.type == OP_CONV || op.type == OP_CONVT) {
             const bool conv = op.type == OP_CONV;
             Tensor& dst = e->tensors[op.dst];
@@ -536,6 +601,7 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             const int taps = conv ? 9 : 1, stride = conv ? op.stride : 1;
             const TileGeom g = tile_geom(B, Ht, Wt, stride, taps);
             ConvArgs ca{};
+            ca.ksplit = 1;
             ca.src0 = src.data; ca.sc0 = src.scale; ca.sh0 = src.shift; ca.C0 = src.C;
             if (op.skip >= 0) { const Tensor& sk = e->tensors[op.skip]; ca.src1 = sk.data; ca.sc1 = sk.scale; ca.sh1 = sk.shift; ca.C1 = sk.C; }
             ca.wp = wts + op.dev_w; ca.bias = wts + op.dev_b; ca.dst = dst.data;
@@ -568,6 +634,11 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
                 ca.stagger = e->stagger;
             }
+            const int ksplit = (split && !e->use_ws && !e->use_pp) ? choose_ksplit(e, op, B, H, W) : 1;
+            if (ksplit > 1) {
+                ca.ksplit = ksplit; ca.kslice_stride = (long long)B * Ht * Wt * op.cout;
+                ca.dst = e->d_partial; ca.part = nullptr;
+            }
             if (smem > 160 * 1024) return fail(TS2D_ERR_INVALID, "op %s: LDS tile of %zu bytes exceeds 160 KiB", op.name.c_str(), smem);
             const int grid = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
             TRY(prof_begin(e, op.name, st));
@@ -593,7 +664,10 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             if (conv) {
                 const int HW = Ht * Wt;
                 TRY(prof_begin(e, op.name + ".stats", st));
-                if (fused) {
+                if (ksplit > 1) {
+                    hipLaunchKernelGGL(splitk_reduce_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, ksplit, ca.kslice_stride,
+                                       wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.data, dst.scale, dst.shift);
+                } else if (fused) {
                     hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
                                        op.cout, B, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 } else {

@@ -40,6 +40,8 @@ struct ConvArgs {
     int PH, PW;           // staged patch dims per image
     float slope;
     const void* wph;      // split-fp16 packed weights [chunk][tap][N][16 hi | 16 lo] (f16x3 kernel only)
+    int ksplit;           // split-K: blockIdx.y = K slice; slice s writes un-biased partials to dst + s * kslice_stride
+    long long kslice_stride;
     int stagger;          // first-round workgroups in SIMD wave slot k start k * stagger * ~1024 cycles late (0 = off)
     const float* oscale;  // device scalar: 1 / (power-of-two weight pre-scale); lives in the weight arena so that it
                           // travels with the multi-GPU weight broadcast (f16x3 kernel only)
@@ -308,6 +310,39 @@ __global__ __launch_bounds__(256) void stats_direct(const float* __restrict__ x,
     __syncthreads();
     if (pl == 0) {
         for (int k = 1; k < 8; ++k) { s += rs[k][threadIdx.x & 31]; q += rq[k][threadIdx.x & 31]; }
+        const double mean = s / HW;
+        double var = q / HW - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double g = gamma[c];
+        scale[(size_t)n * C + c] = (float)(g * rstd);
+        shift[(size_t)n * C + c] = (float)((double)beta[c] - mean * g * rstd);
+    }
+}
+
+// (c) split-K epilogue for the tiny bottleneck layers: fixed-order sum of the S partial outputs + bias -> raw output,
+// and the InstanceNorm scale/shift of that output in the same pass.  Grid (B, C/32), 256 threads = 8 pixel lanes x 32 ch.
+__global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restrict__ partial, int S, long long slice_stride,
+                                                          const float* __restrict__ bias, int C, int HW,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float* __restrict__ dst, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+    const int n = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, pl = threadIdx.x >> 5;
+    __shared__ double rs[8][32], rq[8][32];
+    const float b = bias[c];
+    double s = 0.0, q = 0.0;
+    for (int p = pl; p < HW; p += 8) {
+        const size_t o = ((size_t)n * HW + p) * C + c;
+        float v = 0.f;
+        for (int k = 0; k < S; ++k) v += partial[(size_t)k * slice_stride + o];
+        v += b;
+        dst[o] = v;
+        s += (double)v; q += (double)v * (double)v;
+    }
+    rs[pl][cl] = s; rq[pl][cl] = q;
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < 8; ++k) { s += rs[k][cl]; q += rq[k][cl]; }
         const double mean = s / HW;
         double var = q / HW - mean * mean;
         var = var > 0.0 ? var : 0.0;

@@ -51,7 +51,8 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
-        const float bv = a.bias[co];
+        const float bv = a.ksplit > 1 ? 0.f : a.bias[co];      // split-K partials: bias is added by splitk_reduce_stats
+        float* const obase = a.dst + (size_t)blockIdx.y * a.kslice_stride;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -62,7 +63,7 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
                 const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
                 if (il < NIMG && n < a.B && oy < a.Ht && ox < a.Wt) {
                     const float v = acc_t[mt][nt][i] * oscale + bv;
-                    a.dst[((size_t)(n * a.Ht + oy) * a.Wt + ox) * a.Cout + co] = v;
+                    obase[((size_t)(n * a.Ht + oy) * a.Wt + ox) * a.Cout + co] = v;
                     st_s[nt] += v; st_q[nt] += v * v;
                 }
             }
@@ -177,12 +178,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
         }
     };
 
+    // split-K (tiny layers): this workgroup handles chunks [kbeg, kend) and writes un-biased partials
+    const int kper = (nchunks + a.ksplit - 1) / a.ksplit;
+    const int kbeg = (int)blockIdx.y * kper, kend = (kbeg + kper < nchunks) ? kbeg + kper : nchunks;
 #pragma unroll
-    for (int s = 0; s < PF; ++s) prefetch(s, pv[s]);          // nchunks >= 2 and even (channels are multiples of 32)
-    for (int ch0 = 0; ch0 < nchunks; ch0 += PF) {
+    for (int s = 0; s < PF; ++s) if (kbeg + s < kend) prefetch(kbeg + s, pv[s]);
+    for (int ch0 = kbeg; ch0 < kend; ch0 += PF) {
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
         const int ch = ch0 + s;
+        if (PF > 1 && ch >= kend) break;
         const float* src; const float* sc; const float* sh; int C, cb;
         chunk_src(ch, src, sc, sh, C, cb);
         __syncthreads();   // the previous chunk's MFMA reads of LDS are done
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
             }
         }
         __syncthreads();
-        if (ch + PF < nchunks) prefetch(ch + PF, pv[s]);   // HBM latency hides behind the MFMA phases
+        if (ch + PF < kend) prefetch(ch + PF, pv[s]);      // HBM latency hides behind the MFMA phases
 
         f32x16 acc_c[2][NT];
 #pragma unroll
@@ -384,8 +389,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
         }
     };
 
-    prefetch(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
+    const int kper = (nchunks + a.ksplit - 1) / a.ksplit;
+    const int kbeg = (int)blockIdx.y * kper, kend = (kbeg + kper < nchunks) ? kbeg + kper : nchunks;
+    if (kbeg < kend) prefetch(kbeg);
+    for (int ch = kbeg; ch < kend; ++ch) {
         const int cb = ch * 8;
         __syncthreads();
         {
@@ -439,7 +446,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
             }
         }
         __syncthreads();
-        if (ch + 1 < nchunks) prefetch(ch + 1);
+        if (ch + 1 < kend) prefetch(ch + 1);
 
         f32x16 acc_c[2][NT];
 #pragma unroll

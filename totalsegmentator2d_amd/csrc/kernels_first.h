@@ -1,0 +1,134 @@
+// First conv block (Conv2d C->f0, C = 1..4 input channels, 3x3, stride 1) on the exact fp32 MFMA.
+// K = 9*C is tiny, so the layer is HBM-bound on its OUTPUT (33.5 MB per 512x512 slice).  The generic kernel padded C to 8
+// (K = 72) and needed a separate NCHW->NHWC pass; here each tap is ONE v_mfma_f32_32x32x2_f32 per channel pair
+// (k = the two channels), the patch is read straight from the NCHW boundary tensor, and the weights live in registers
+// (one float per lane per (tap, pair, column tile)).  The network input is not normalised, so there is no prologue math.
+#pragma once
+#include "kernels.h"
+
+namespace ts2d {
+
+struct FirstArgs {
+    const float* x;       // NCHW [B, C, H, W] (the boundary input)
+    const float* w;       // PyTorch layout [Cout][C][3][3]
+    const float* bias;    // [Cout]
+    float* dst;           // raw NHWC [B, H, W, Cout]
+    float* part;          // partial statistics [n][tile][Cout][2] or nullptr (tile spans several images)
+    int B, C, H, W, Cout;
+    int lgTH, lgTW, lgNIMG, tiles_x, tiles_y, n_mtiles, PH, PW;
+};
+
+template <int NT, int KP>      // NT = Cout / 32 column tiles, KP = ceil(C / 2) channel pairs
+__global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
+    constexpr int CP = 2 * KP + 1;               // floats per patch pixel (+1 pad: conflict-free ds_read_b32)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int mtile = blockIdx.x;
+    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW, NIMG = 1 << a.lgNIMG;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int grp = mtile / tpi, tin = mtile - grp * tpi;
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
+    const int nimg0 = grp << a.lgNIMG;
+    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int PHW = a.PH * a.PW, P = PHW << a.lgNIMG;
+
+    // weights -> registers: B[k = h][j = r] of (tap, pair kp, column tile nt) = w[co = 32 nt + r][c = 2 kp + h][tap]
+    float wr[9][KP][NT];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = 2 * kp + h;
+                wr[tap][kp][nt] = c < a.C ? a.w[((size_t)(nt * 32 + r) * a.C + c) * 9 + tap] : 0.f;
+            }
+
+    // patch: NCHW planes -> LDS [pixel][2*KP (+pad)], zeros outside the image / beyond C
+    const float inv_phw = 1.0f / (float)PHW, inv_pw = 1.0f / (float)a.PW;
+    for (int idx = tid; idx < P * 2 * KP; idx += kBlock) {
+        const int c = idx / P, pp = idx - c * P;                       // plane-major: consecutive threads walk a row
+        const int il = (int)(((float)pp + 0.5f) * inv_phw), rem = pp - il * PHW;
+        const int py = (int)(((float)rem + 0.5f) * inv_pw), px = rem - py * a.PW;
+        const int n = nimg0 + il, iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+        float v = 0.f;
+        if (c < a.C && n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            v = a.x[((size_t)(n * a.C + c) * a.H + iy) * a.W + ix];
+        smem[pp * CP + c] = v;
+    }
+    __syncthreads();
+
+    int abase[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = 64 * w + 32 * mt + r;
+        const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+        abase[mt] = (il < NIMG ? (il * PHW + ty * a.PW + tx) * CP : 0) + h;
+    }
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int toff = ((tap / 3) * a.PW + (tap % 3)) * CP;
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            float av[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) av[mt] = smem[abase[mt] + toff + 2 * kp];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], wr[tap][kp][nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    float st_s[NT], st_q[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 32 + r;
+        const float bv = a.bias[co];
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int m = 64 * w + 32 * mt + row;
+                const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+                const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
+                if (il < NIMG && n < a.B && oy < a.H && ox < a.W) {
+                    const float v = acc[mt][nt][i] + bv;
+                    a.dst[((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + co] = v;
+                    ss += v; qq += v * v;
+                }
+            }
+        }
+        st_s[nt] = ss; st_q[nt] = qq;
+    }
+    if (a.part != nullptr) {
+        __syncthreads();
+        float* red = smem;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s = st_s[nt], q = st_q[nt];
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (h == 0) { red[(w * NT * 32 + nt * 32 + r) * 2] = s; red[(w * NT * 32 + nt * 32 + r) * 2 + 1] = q; }
+        }
+        __syncthreads();
+        if (tid < NT * 32) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) { s += red[(ww * NT * 32 + tid) * 2]; q += red[(ww * NT * 32 + tid) * 2 + 1]; }
+            float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + tid) * 2;
+            p[0] = s; p[1] = q;
+        }
+    }
+}
+
+}  // namespace ts2d
