@@ -1,0 +1,68 @@
+"""Output side of the hot path: logits -> segmentation image.
+
+Reference: ``export_prediction_from_logits(prediction, data_properties, configuration_manager, plans_manager, dataset_json,
+ofile_truncated, save_probabilities)`` called at ``ts2d/core/inference/prediction_worker.py:215-221`` (third-party
+nnunetv2ml fork: multilabel => ``sigmoid(logits.float()) > 0.5`` per channel), followed by the metadata restamp
+``set_annotation_meta(img, labels, colors)`` at ``prediction_worker.py:226-240``.  Here both happen in memory; the
+file is written once.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import nrrd
+from .image import set_annotation_meta
+
+SIGMOID_HALF_THRESHOLD = np.float32(1.5 * 2.0 ** -24)     # sigmoid(float32 x) > 0.5  <=>  x > 1.5 * 2^-24 (tests/test_oracle.py)
+
+
+def convert_predicted_logits_to_segmentation_with_correct_shape(logits, properties: dict, multilabel: bool = True,
+                                                                transpose_backward=(0, 1, 2)) -> np.ndarray:
+    """[K, Z, H, W] logits (any float dtype) -> uint8 segmentation in the ORIGINAL (pre-crop) array shape:
+    multilabel: [K, Z0, H0, W0] of {0,1}; otherwise a label map [Z0, H0, W0] (argmax).  The resampling step of upstream
+    is a no-op for the shapes this engine accepts (preprocess.py refuses spacing changes)."""
+    lg = np.asarray(logits).astype(np.float32)
+    shape0 = tuple(properties['shape_before_cropping'])
+    bbox = properties['bbox_used_for_cropping']
+    sl = tuple(slice(b[0], b[1]) for b in bbox)
+    if multilabel:
+        seg = (lg > SIGMOID_HALF_THRESHOLD).astype(np.uint8)
+        out = np.zeros((lg.shape[0],) + shape0, dtype=np.uint8)
+        out[(slice(None),) + sl] = seg
+        return out.transpose([0] + [i + 1 for i in transpose_backward])
+    seg = lg.argmax(0).astype(np.uint8)
+    out = np.zeros(shape0, dtype=np.uint8)
+    out[sl] = seg
+    return out.transpose(list(transpose_backward))
+
+
+def segmentation_to_image(seg: np.ndarray, ref: nrrd.Image, multilabel: bool, labels: Optional[Dict[int, str]] = None,
+                          colors: Optional[dict] = None) -> nrrd.Image:
+    """uint8 array from :func:`convert_...` -> image with the geometry of the (2-D) input image `ref` and Slicer metadata."""
+    if multilabel:
+        arr = np.moveaxis(seg, 0, -1)                  # [Z, H, W, K]
+        if ref.dimension == 2:
+            arr = arr[0]                               # [H, W, K]
+        img = nrrd.Image(np.ascontiguousarray(arr), ref.spacing, ref.origin, ref.direction, seg.shape[0], {}, ref.space)
+    else:
+        arr = seg[0] if ref.dimension == 2 else seg
+        img = nrrd.Image(np.ascontiguousarray(arr), ref.spacing, ref.origin, ref.direction, 1, {}, ref.space)
+    if labels or colors:
+        set_annotation_meta(img, {int(k): v for k, v in (labels or {}).items()}, colors)
+    return img
+
+
+def export_prediction_from_logits(logits, properties: dict, configuration_manager, plans_manager, dataset_json: dict,
+                                  ofile_truncated: str, save_probabilities: bool = False, ref_image: Optional[nrrd.Image] = None,
+                                  labels: Optional[Dict[int, str]] = None, colors: Optional[dict] = None) -> nrrd.Image:
+    multilabel = bool(dataset_json.get('multilabel', dataset_json.get('multiclass', False)))
+    tb = getattr(plans_manager, 'transpose_backward', [0, 1, 2])
+    seg = convert_predicted_logits_to_segmentation_with_correct_shape(logits, properties, multilabel, tb)
+    if ref_image is None:
+        ref_image = nrrd.read(properties['sitk_stuff']['files'][0])
+    img = segmentation_to_image(seg, ref_image, multilabel, labels, colors)
+    if ofile_truncated:
+        nrrd.write(img, ofile_truncated + dataset_json.get('file_ending', '.nrrd'), True)
+    return img

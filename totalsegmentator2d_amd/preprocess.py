@@ -15,6 +15,22 @@ import numpy as np
 from . import nrrd
 
 
+def image_to_array(img) -> Tuple[np.ndarray, dict]:
+    """One in-memory image -> (``[c, z, y, x]`` float32, properties); 2-D images get a unit z axis and nnU-Net's
+    ``999`` pseudo-spacing."""
+    a = np.asarray(img.array)
+    if img.dimension == 2:
+        a = a[None] if img.components == 1 else np.moveaxis(a, -1, 0)
+        a = a[:, None]
+        sp = (999.0, float(img.spacing[1]), float(img.spacing[0]))
+    elif img.dimension == 3:
+        a = a[None] if img.components == 1 else np.moveaxis(a, -1, 0)
+        sp = (float(img.spacing[2]), float(img.spacing[1]), float(img.spacing[0]))
+    else:
+        raise RuntimeError(f"unsupported image dimension {img.dimension}")
+    return a.astype(np.float32), {'spacing': sp, 'sitk_stuff': {'files': []}}
+
+
 def read_images(files: Sequence[str]) -> Tuple[np.ndarray, dict]:
     """The fork's reader for one multi-component 2-D file (reference ``ts2d/tool.py:160,170-172`` hands the model ONE
     vector image): ``[y, x, c]`` -> ``[c, 1, y, x]``; spacing reported nnU-Net style ``(999, sy, sx)`` for 2-D."""
