@@ -90,7 +90,7 @@ def main():
     if world != args.gpus:
         if args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
-    multi = world > 1
+    multi = world > 1 or os.environ.get('TS2D_FORCE_DIST') == '1'      # the flag rehearses the RCCL path on one GPU
     if multi:
         parallel.init_process_group('nccl')
     torch.cuda.set_device(local_rank)
@@ -104,12 +104,23 @@ def main():
         engine = Engine(arch, weights.pack_blob(arch, sd), device=local_rank)
     else:
         engine = Engine(arch, None, device=local_rank)
+    if os.environ.get('TS2D_FORCE_DIST') == '1' and world == 1:
+        # rehearsal: a second, empty replica on the same GPU receives the arena by device copy after the (self) broadcast
+        replica = Engine(arch, None, device=local_rank)
     bcast_ms = None
     if multi:
         dist.barrier()
         t0 = time.time()
         parallel.broadcast_engine_weights(engine, src=0)                   # one RCCL broadcast over xGMI
         bcast_ms = (time.time() - t0) * 1e3
+        if os.environ.get('TS2D_FORCE_DIST') == '1' and world == 1:
+            ps, ns = engine.weight_buffer(); pd, nd = replica.weight_buffer()
+            torch.as_tensor(parallel._DevicePtrTensor(pd, nd), device=dev).copy_(torch.as_tensor(parallel._DevicePtrTensor(ps, ns), device=dev))
+            torch.cuda.synchronize(dev); replica.weights_ready()
+            xa = torch.randn(2, 2, 512, 512, device=dev)
+            la, _ = engine.forward(xa); lb, _ = replica.forward(xa); torch.cuda.synchronize(dev)
+            assert torch.equal(la, lb), 'replica filled through the broadcast hook differs'
+            replica.close()
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn(B, 2, H, W, device=dev, generator=gen)                 # synthetic N(0,1) = post-z-score statistics
     logits = torch.empty(B, arch.num_classes, H, W, device=dev)

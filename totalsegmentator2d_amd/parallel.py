@@ -39,8 +39,21 @@ def init_process_group(backend: Optional[str] = None):
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     rank, local_rank, world = env_rank_world()
     if backend == 'nccl':
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        # RCCL prints a version banner on STDOUT when the communicator is created; bench.py's contract is ONE JSON line on
+        # stdout, so fd 1 points at stderr while RCCL initialises (init + first collective), then is restored.
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
 
