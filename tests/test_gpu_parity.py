@@ -140,3 +140,33 @@ def test_weight_broadcast_hook_single_rank():
         src.load_weights(blob * 0.5)                                                  # fold switch
         c, _ = src.forward(x)
         assert not np.array_equal(a, c)
+
+
+@pytest.mark.parametrize('K,seed', [(23, 2), (26, 4)])
+def test_config3_other_submodel_heads(K, seed):
+    """BASELINE config 3 geometry: the other ts2d-v2 sub-models differ only in the number of heads (18/23/24/26/26)."""
+    from oracle import torch_oracle as O
+    arch = UNetArch.canonical(num_classes=K)
+    sd, blob = blob_for(arch, seed)
+    x = cases.make_input(arch, 1, 512, 512, seed)
+    with Engine(arch, blob) as e:
+        lg, mk = e.forward(x, logits=True, mask=True)
+    ref = O.unet_forward(arch, sd, x).numpy()
+    assert lg.shape == (1, K, 512, 512) and np.abs(lg - ref).max() <= TOL
+    assert np.array_equal(unpack_mask(mk, 512), _oracle_mask(lg))
+
+
+def test_config5_tsxr_geometry_9_stages_1024():
+    """BASELINE config 5 geometry (tsxr: 1-channel 1024x1024, 9 stages, K=26), fp32 path."""
+    from oracle import torch_oracle as O
+    arch = UNetArch.canonical(input_channels=1, num_classes=26, n_stages=9)
+    sd, blob = blob_for(arch, 7)
+    x = cases.make_input(arch, 1, 1024, 1024, 7)
+    with Engine(arch, blob) as e:
+        lg, mk = e.forward(x, logits=True, mask=True)
+        for mode in ('exact',):
+            e.set_precision(mode)
+            lg2, _ = e.forward(x, logits=True)
+    ref = O.unet_forward(arch, sd, x).numpy()
+    assert np.abs(lg - ref).max() <= TOL and np.abs(lg2 - ref).max() <= TOL
+    assert np.array_equal(unpack_mask(mk, 1024), _oracle_mask(lg))
