@@ -95,6 +95,21 @@ int ts2d_engine_weights_ready(ts2d_engine* e);
 int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W, float* logits,
                         uint32_t* mask_packed, int on_device, void* stream);
 
+/* Sliding-window inference of ONE preprocessed 2-D image on the device (replaces the body of nnU-Net's
+ * predict_sliding_window_return_logits + _internal_maybe_mirror_and_predict for one fold: reference call site
+ * ts2d/core/inference/prediction_worker.py:209; SURVEY.md rows A3-A5, and A7 for `seg`).
+ *   image          host [C, Hp, Wp] fp32, already padded to at least the patch (pad_nd_image is the caller's job)
+ *   tile_y/tile_x  host, n_tiles tile origins in upstream order (compute_steps_for_sliding_window)
+ *   mirror_mask    bit 0: mirror spatial axis 0 (H), bit 1: axis 1 (W); variants run in upstream order H, W, HW
+ *   gaussian_f16   host [patch_h, patch_w] IEEE half bits (compute_gaussian), or NULL for no weighting
+ *   logits_f16     host [K, Hp, Wp] half bits: aggregated logits / n_predictions, bit-identical to upstream's float16
+ *                  accumulation; may be NULL
+ *   seg_u8         host [K, Hp, Wp]: sigmoid(float(logit)) > 0.5 of the aggregated logits (multilabel export); may be NULL
+ * All tiles x mirror variants go through the network as one batch (chunks of at most 64 rows).  Synchronous. */
+int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp, int patch_h, int patch_w, int n_tiles,
+                              const int32_t* tile_y, const int32_t* tile_x, int mirror_mask, const uint16_t* gaussian_f16,
+                              uint16_t* logits_f16, uint8_t* seg_u8);
+
 /* Pre-allocate the activation workspace for (B, H, W) (reference warm-up contract: a zero patch is pushed through
  * the predictor once at start-up, prediction_worker.py:74-96,136-138). */
 int ts2d_engine_reserve(ts2d_engine* e, int B, int H, int W);

@@ -1,0 +1,35 @@
+"""End-to-end per-case latency of TS2D.predict() with five canonical sub-models (K = 18/23/24/26/26, synthetic weights) on
+the reference's sample_s0616.nrrd (2 tiles x 4 mirror passes per sub-model): the counterpart of the reference's
+"0.5-0.9 s per case on an RTX 4090" (README.md:43-46)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from totalsegmentator2d_amd import weights
+from totalsegmentator2d_amd.arch import UNetArch
+from totalsegmentator2d_amd.model import HIPModel
+from totalsegmentator2d_amd.tool import TS2D
+
+groups = [('cardiac', 18), ('muscles', 23), ('organs', 24), ('ribs', 26), ('vertebrae', 26)]
+models = {}
+for i, (g, K) in enumerate(groups):
+    arch = UNetArch.canonical(num_classes=K)
+    blob = (np.random.default_rng(i).standard_normal(arch.n_params()) * 0.02).astype(np.float32)
+    ds = {'channel_names': {'0': 'mean', '1': 'max'}, 'labels': {'background': 0, **{f'{g}_{j+1}': j + 1 for j in range(K)}},
+          'file_ending': '.nrrd', 'multilabel': True}
+    models[f'ts2d-v2-ep4000b2_{g}'] = HIPModel({'model': f'ts2d-v2-ep4000b2_{g}', 'revision': 1, 'param': {},
+                                               'synthetic': {'arch': arch, 'blobs': [blob], 'patch_size': (512, 512), 'dataset_json': ds}})
+t0 = time.time()
+with TS2D(models=models) as ts:
+    print(f'startup {time.time() - t0:.2f} s', flush=True)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'assets', 'sample_s0616.nrrd')
+    for it in range(3):
+        t = time.time()
+        res = ts.predict(path)
+        dt = time.time() - t
+        stages = {}
+        for m, r in res.data['models'].items():
+            ts_ = r['timestamps']
+            for a, b in (('start', 'preprocessed'), ('preprocessed', 'predicted'), ('predicted', 'exported')):
+                stages[b] = stages.get(b, 0) + ts_[b] - ts_[a]
+        print(f'case {it}: {dt:.3f} s  (preprocess {stages["preprocessed"]:.3f}, predict {stages["predicted"]:.3f}, export {stages["exported"]:.3f}); '
+              f'segmentation {res.get_segmentation().components} labels', flush=True)

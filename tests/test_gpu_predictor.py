@@ -55,3 +55,27 @@ def test_config1_sample_s0616_canonical_net():
     seg = (out.astype(np.float32) > 1.5 * 2.0 ** -24)
     seg_ref = O.logits_to_mask(ref).numpy().astype(bool)
     assert (seg != seg_ref).mean() < 1e-3
+
+
+@pytest.mark.parametrize('name', list(cases.SW_CASES))
+def test_device_aggregation_is_bit_identical_to_host_aggregation(name):
+    """The device-side gather / mirror-average / fp16 Gaussian aggregation (ts2d_engine_predict_tiled) against the host
+    numpy implementation fed with the SAME engine's per-tile logits: must agree bit for bit (same half arithmetic, same
+    tile order)."""
+    arch, shape, patch, step, mirror, folds, seed = cases.SW_CASES[name]
+    blobs = [blob_for(arch, seed + f)[1] for f in range(folds)]
+    data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
+    dev = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None)
+    dev.manual_initialization(arch, blobs, patch, inference_allowed_mirroring_axes=mirror)
+    try:
+        engines = dev.engines
+
+        def net(batch, fold):
+            return engines[fold].forward(np.ascontiguousarray(batch))[0]
+        host = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, network=net)
+        host.manual_initialization(arch, blobs, patch, inference_allowed_mirroring_axes=mirror)
+        a = dev.predict_logits_from_preprocessed_data(data).cpu().numpy()
+        b = host.predict_logits_from_preprocessed_data(data).cpu().numpy()
+    finally:
+        dev.close()
+    assert a.dtype == b.dtype == np.float16 and np.array_equal(a, b)

@@ -19,7 +19,7 @@ PRECISION_F32_SPLIT_F16X3 = 1
 
 # every symbol include/ts2d_engine.h declares
 SYMBOLS = ('ts2d_engine_create', 'ts2d_engine_load_weights', 'ts2d_engine_weight_buffer', 'ts2d_engine_weights_ready',
-           'ts2d_engine_forward', 'ts2d_engine_reserve', 'ts2d_engine_set_precision', 'ts2d_engine_set_profiling', 'ts2d_engine_num_ops',
+           'ts2d_engine_forward', 'ts2d_engine_predict_tiled', 'ts2d_engine_reserve', 'ts2d_engine_set_precision', 'ts2d_engine_set_profiling', 'ts2d_engine_num_ops',
            'ts2d_engine_op_name', 'ts2d_engine_op_times', 'ts2d_engine_debug_tensor', 'ts2d_engine_device_bytes', 'ts2d_engine_destroy',
            'ts2d_last_error', 'ts2d_abi_version')
 
@@ -76,6 +76,9 @@ def load():
     lib.ts2d_engine_forward.restype = c.c_int
     lib.ts2d_engine_forward.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_void_p,
                                         c.c_int, c.c_void_p]
+    lib.ts2d_engine_predict_tiled.restype = c.c_int
+    lib.ts2d_engine_predict_tiled.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_void_p,
+                                              c.c_int, c.c_void_p, c.c_void_p, c.c_void_p]
     lib.ts2d_engine_reserve.restype = c.c_int
     lib.ts2d_engine_reserve.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int]
     lib.ts2d_engine_set_precision.restype = c.c_int

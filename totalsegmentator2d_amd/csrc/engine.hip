@@ -8,6 +8,7 @@
 #include "kernels_f16x3_convt.h"
 #include "kernels_f16x3_pp.h"
 #include "kernels_first.h"
+#include "kernels_sw.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -94,6 +95,7 @@ struct ts2d_engine {
     bool profiling = false;
     std::vector<Launch> launches; size_t n_launched = 0;
     int lastB = 0, lastH = 0, lastW = 0; hipStream_t last_stream = nullptr;
+    char* d_sw = nullptr; size_t sw_bytes = 0;     // sliding-window scratch (image, batch, tile logits, outputs)
 };
 
 namespace {
@@ -803,6 +805,70 @@ int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W,
     return TS2D_OK;
 }
 
+int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp, int ph, int pw, int n_tiles,
+                              const int32_t* tile_y, const int32_t* tile_x, int mirror_mask, const uint16_t* gaussian_f16,
+                              uint16_t* logits_f16, uint8_t* seg_u8) {
+    if (!e || !image || !tile_y || !tile_x) return fail(TS2D_ERR_INVALID, "ts2d_engine_predict_tiled: null argument");
+    if (!e->weights_ready) return fail(TS2D_ERR_STATE, "ts2d_engine_predict_tiled: weights not loaded");
+    if (!logits_f16 && !seg_u8) return fail(TS2D_ERR_INVALID, "ts2d_engine_predict_tiled: both outputs are null");
+    if (n_tiles < 1 || ph > Hp || pw > Wp) return fail(TS2D_ERR_INVALID, "bad tiling: %d tiles of %dx%d on %dx%d", n_tiles, ph, pw, Hp, Wp);
+    for (int t = 0; t < n_tiles; ++t)
+        if (tile_y[t] < 0 || tile_x[t] < 0 || tile_y[t] + ph > Hp || tile_x[t] + pw > Wp)
+            return fail(TS2D_ERR_INVALID, "tile %d at (%d,%d) leaves the %dx%d image", t, tile_y[t], tile_x[t], Hp, Wp);
+    const int C = e->arch.input_channels, K = e->arch.num_classes;
+    int vflip[4] = {0, 0, 0, 0}, V = 1;
+    if ((mirror_mask & 3) == 3) { vflip[1] = 1; vflip[2] = 2; vflip[3] = 3; V = 4; }
+    else if (mirror_mask & 1) { vflip[1] = 1; V = 2; }
+    else if (mirror_mask & 2) { vflip[1] = 2; V = 2; }
+    const int rows = n_tiles * V, chunk = std::min(rows, 64);
+    TRY(ts2d_engine_reserve(e, chunk, ph, pw));
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    // scratch layout
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_img = take((size_t)C * Hp * Wp * 4), o_batch = take((size_t)rows * C * ph * pw * 4);
+    const size_t o_log = take((size_t)rows * K * ph * pw * 4), o_g = take((size_t)ph * pw * 2);
+    const size_t o_o16 = take((size_t)K * Hp * Wp * 2), o_seg = take((size_t)K * Hp * Wp);
+    const size_t o_ty = take((size_t)n_tiles * 4), o_tx = take((size_t)n_tiles * 4), o_vf = take(16);
+    if (off > e->sw_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (e->d_sw) { HIP_TRY(hipFree(e->d_sw)); e->d_sw = nullptr; e->sw_bytes = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_sw), off));
+        e->sw_bytes = off;
+    }
+    char* b = e->d_sw;
+    float* d_img = reinterpret_cast<float*>(b + o_img); float* d_batch = reinterpret_cast<float*>(b + o_batch);
+    float* d_log = reinterpret_cast<float*>(b + o_log); __half* d_g = reinterpret_cast<__half*>(b + o_g);
+    __half* d_o16 = reinterpret_cast<__half*>(b + o_o16); uint8_t* d_seg = reinterpret_cast<uint8_t*>(b + o_seg);
+    int* d_ty = reinterpret_cast<int*>(b + o_ty); int* d_tx = reinterpret_cast<int*>(b + o_tx); int* d_vf = reinterpret_cast<int*>(b + o_vf);
+    HIP_TRY(hipMemcpyAsync(d_img, image, (size_t)C * Hp * Wp * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_ty, tile_y, (size_t)n_tiles * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_tx, tile_x, (size_t)n_tiles * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_vf, vflip, 16, hipMemcpyHostToDevice, st));
+    if (gaussian_f16) HIP_TRY(hipMemcpyAsync(d_g, gaussian_f16, (size_t)ph * pw * 2, hipMemcpyHostToDevice, st));
+    {
+        const long long total = (long long)rows * C * ph * pw;
+        hipLaunchKernelGGL(sw_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_img, C, Hp, Wp, ph, pw, V, d_ty, d_tx, d_vf, d_batch, total);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int r0 = 0; r0 < rows; r0 += chunk) {
+        const int nb = std::min(chunk, rows - r0);
+        TRY(run_forward(e, d_batch + (size_t)r0 * C * ph * pw, nb, ph, pw, d_log + (size_t)r0 * K * ph * pw, nullptr, st));
+    }
+    {
+        const long long total = (long long)K * Hp * Wp;
+        hipLaunchKernelGGL(sw_aggregate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_log, K, Hp, Wp, ph, pw, n_tiles, V,
+                           d_ty, d_tx, d_vf, gaussian_f16 ? d_g : nullptr, logits_f16 ? d_o16 : nullptr, seg_u8 ? d_seg : nullptr,
+                           kSigmoidHalfThreshold, total);
+        HIP_TRY(hipGetLastError());
+    }
+    if (logits_f16) HIP_TRY(hipMemcpyAsync(logits_f16, d_o16, (size_t)K * Hp * Wp * 2, hipMemcpyDeviceToHost, st));
+    if (seg_u8) HIP_TRY(hipMemcpyAsync(seg_u8, d_seg, (size_t)K * Hp * Wp, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return TS2D_OK;
+}
+
 int ts2d_engine_set_profiling(ts2d_engine* e, int enable) {
     if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_profiling: null engine");
     e->profiling = enable != 0;
@@ -854,7 +920,7 @@ int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_
     return TS2D_OK;
 }
 
-size_t ts2d_engine_device_bytes(ts2d_engine* e) { return e ? e->weight_floats * sizeof(float) + e->ws_bytes : 0; }
+size_t ts2d_engine_device_bytes(ts2d_engine* e) { return e ? e->weight_floats * sizeof(float) + e->ws_bytes + e->sw_bytes : 0; }
 
 int ts2d_engine_destroy(ts2d_engine* e) {
     if (!e) return TS2D_OK;
@@ -862,6 +928,7 @@ int ts2d_engine_destroy(ts2d_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (Launch& l : e->launches) { if (l.e0) (void)hipEventDestroy(l.e0); if (l.e1) (void)hipEventDestroy(l.e1); }
     if (e->d_ws) (void)hipFree(e->d_ws);
+    if (e->d_sw) (void)hipFree(e->d_sw);
     if (e->d_weights) (void)hipFree(e->d_weights);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;

@@ -126,6 +126,30 @@ class Engine:
             out_mask.ctypes.data if mask else None, 0, None), 'ts2d_engine_forward')
         return (out_logits if logits else None), (out_mask if mask else None)
 
+    def predict_tiled(self, image: np.ndarray, patch, tiles, mirror_axes=None, gaussian: Optional[np.ndarray] = None,
+                      want_logits: bool = True, want_seg: bool = False):
+        """Device-side sliding window for one padded 2-D image [C,Hp,Wp] (C-ABI ts2d_engine_predict_tiled).
+        tiles: [(y, x), ...] in upstream order; gaussian: float16 [ph,pw] or None.  Returns (float16 [K,Hp,Wp] or None,
+        uint8 [K,Hp,Wp] or None)."""
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        C, Hp, Wp = image.shape
+        if C != self.arch.input_channels:
+            raise RuntimeError(f"input has {C} channels, the model expects {self.arch.input_channels}")
+        ty = np.ascontiguousarray([t[0] for t in tiles], dtype=np.int32)
+        tx = np.ascontiguousarray([t[1] for t in tiles], dtype=np.int32)
+        mask = 0
+        for a in (mirror_axes or ()):
+            mask |= 1 << int(a)
+        g = None if gaussian is None else np.ascontiguousarray(gaussian, dtype=np.float16)
+        K = self.arch.num_classes
+        out16 = np.empty((K, Hp, Wp), dtype=np.float16) if want_logits else None
+        seg = np.empty((K, Hp, Wp), dtype=np.uint8) if want_seg else None
+        _lib.check(self.lib.ts2d_engine_predict_tiled(
+            self._h, image.ctypes.data, Hp, Wp, int(patch[0]), int(patch[1]), len(tiles), ty.ctypes.data, tx.ctypes.data, mask,
+            None if g is None else g.ctypes.data, None if out16 is None else out16.ctypes.data,
+            None if seg is None else seg.ctypes.data), 'ts2d_engine_predict_tiled')
+        return out16, seg
+
     def _check_shape(self, C, W, mask):
         if C != self.arch.input_channels:
             raise RuntimeError(f"input has {C} channels, the model expects {self.arch.input_channels}")

@@ -161,6 +161,20 @@ class HIPnnUNetPredictor:
         if self.use_mirroring and self.allowed_mirroring_axes and max(self.allowed_mirroring_axes) > 1:
             raise AssertionError('mirror_axes does not match the dimension of the input!')
         nv = len(combos)
+        if self._network_override is None:
+            # product path: gather (with mirroring), network, mirror-average and fp16 Gaussian aggregation all on the device
+            g = sw.compute_gaussian(patch) if self.use_gaussian else None
+            K = self.arch.num_classes
+            logits = np.empty((K, Z, H, W), dtype=np.float16)
+            axes = self.allowed_mirroring_axes if self.use_mirroring else None
+            for d in range(Z):
+                tiles = [(sx, sy) for (dd, sx, sy) in slicers if dd == d]
+                out16, _ = self.engines[fold].predict_tiled(padded[:, d], patch, tiles, axes, g, want_logits=True)
+                logits[:, d] = out16
+            if np.any(np.isinf(logits)):
+                raise RuntimeError('Encountered inf in predicted array. Aborting... If this problem persists, reduce '
+                                   'value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits to fp32')
+            return logits[(slice(None),) + revert[1:]]
         batch = np.empty((len(slicers) * nv, C, patch[0], patch[1]), dtype=np.float32)
         for t, (d, sx, sy) in enumerate(slicers):
             x = padded[:, d, sx:sx + patch[0], sy:sy + patch[1]]
