@@ -37,11 +37,17 @@ def _gaussian_kernel1d(sigma: float, radius: int) -> np.ndarray:
     return phi / phi.sum()
 
 
+_GAUSS_CACHE = {}
+
+
 def compute_gaussian(tile_size: Sequence[int], sigma_scale: float = 1. / 8, value_scaling_factor: float = 10,
                      dtype=np.float16) -> np.ndarray:
     """Gaussian importance map: ``gaussian_filter`` (truncate 4 sigma, mode constant) of a centre delta, divided by
     max / value_scaling_factor, cast to ``dtype`` (float16 upstream), zeros replaced by the smallest non-zero value.
     Filtering a delta is separable, so the map is the outer product of the 1-D kernels - no scipy needed."""
+    key = (tuple(int(t) for t in tile_size), float(sigma_scale), float(value_scaling_factor), np.dtype(dtype).str)
+    if key in _GAUSS_CACHE:
+        return _GAUSS_CACHE[key]
     axes = []
     for n in tile_size:
         sigma = n * sigma_scale
@@ -62,6 +68,8 @@ def compute_gaussian(tile_size: Sequence[int], sigma_scale: float = 1. / 8, valu
     mask = g == 0
     if mask.any():
         g[mask] = g[~mask].min()
+    g.setflags(write=False)
+    _GAUSS_CACHE[key] = g
     return g
 
 
