@@ -258,17 +258,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = ((tap / 3) * a.PW + (tap % 3)) * kRec;
+            // fragment reads in first-use order (lo*hi products first): the MFMAs can start after two reads have landed
             half8 ah[2], al[2], bh[NT], bl[NT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                ah[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff);
-                al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff + 32);
-            }
+            for (int mt = 0; mt < 2; ++mt) al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff + 32);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bh[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase);
-                bl[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase + 32);
-            }
+            for (int nt = 0; nt < NT; ++nt) bh[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) ah[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bl[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase + 32);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
