@@ -16,6 +16,7 @@ ABI_VERSION = 1
 MAX_STAGES = 16
 PRECISION_F32_EXACT = 0
 PRECISION_F32_SPLIT_F16X3 = 1
+PRECISION_F16 = 2
 
 # every symbol include/ts2d_engine.h declares
 SYMBOLS = ('ts2d_engine_create', 'ts2d_engine_load_weights', 'ts2d_engine_weight_buffer', 'ts2d_engine_weights_ready',

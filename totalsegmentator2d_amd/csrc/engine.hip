@@ -94,7 +94,7 @@ struct ts2d_engine {
     hipStream_t stream = nullptr;
     bool profiling = false;
     std::vector<Launch> launches; size_t n_launched = 0;
-    int lastB = 0, lastH = 0, lastW = 0; hipStream_t last_stream = nullptr;
+    int lastB = 0, lastH = 0, lastW = 0; hipStream_t last_stream = nullptr; bool last_f16 = false;
     char* d_sw = nullptr; size_t sw_bytes = 0;     // sliding-window scratch (image, batch, tile logits, outputs)
 };
 
@@ -376,10 +376,10 @@ hipError_t launch_conv(int taps, int stride, int ck, int bn, const ConvArgs& a, 
     return hipErrorInvalidConfiguration;
 }
 
-template <int BN, int MAXU, int PF = 1>
+template <int BN, int MAXU, typename ST, int NP>
 hipError_t launch_split_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv3x3_f16x3<BN, MAXU, PF>;
+    auto kern = conv3x3_f16x3<BN, MAXU, 1, ST, NP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -389,18 +389,22 @@ hipError_t launch_split_inst(const ConvArgs& a, int grid, size_t smem, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_split(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    if (bn == 32 && maxu == 3) return launch_split_inst<32, 3>(a, grid, smem, st);      // (PF = 2 measured slower: 2 instead of 3 workgroups/CU)
-    if (bn == 32 && maxu == 5) return launch_split_inst<32, 5>(a, grid, smem, st);
-    if (bn == 64 && maxu == 3) return launch_split_inst<64, 3>(a, grid, smem, st);
-    if (bn == 64 && maxu == 5) return launch_split_inst<64, 5>(a, grid, smem, st);
+template <typename ST, int NP>
+hipError_t launch_split_t(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    if (bn == 32 && maxu == 3) return launch_split_inst<32, 3, ST, NP>(a, grid, smem, st);   // (2-chunk prefetch measured slower)
+    if (bn == 32 && maxu == 5) return launch_split_inst<32, 5, ST, NP>(a, grid, smem, st);
+    if (bn == 64 && maxu == 3) return launch_split_inst<64, 3, ST, NP>(a, grid, smem, st);
+    if (bn == 64 && maxu == 5) return launch_split_inst<64, 5, ST, NP>(a, grid, smem, st);
     return hipErrorInvalidConfiguration;
 }
+hipError_t launch_split(bool f16, int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    return f16 ? launch_split_t<_Float16, 1>(bn, maxu, a, grid, smem, st) : launch_split_t<float, 3>(bn, maxu, a, grid, smem, st);
+}
 
-template <int BN, int MAXU>
+template <int BN, int MAXU, typename ST, int NP>
 hipError_t launch_split_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv3x3s2_f16x3<BN, MAXU>;
+    auto kern = conv3x3s2_f16x3<BN, MAXU, ST, NP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -450,12 +454,21 @@ hipError_t launch_split_pp(int bn, int maxu, const ConvArgs& a, int grid, size_t
     return hipErrorInvalidConfiguration;
 }
 
-hipError_t launch_split_s2(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    if (bn == 32 && maxu == 5) return launch_split_s2_inst<32, 5>(a, grid, smem, st);
-    if (bn == 32 && maxu == 6) return launch_split_s2_inst<32, 6>(a, grid, smem, st);
-    if (bn == 64 && maxu == 5) return launch_split_s2_inst<64, 5>(a, grid, smem, st);
-    if (bn == 64 && maxu == 6) return launch_split_s2_inst<64, 6>(a, grid, smem, st);
+template <typename ST, int NP>
+hipError_t launch_split_s2_t(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    if (bn == 32 && maxu == 5) return launch_split_s2_inst<32, 5, ST, NP>(a, grid, smem, st);
+    if (bn == 32 && maxu == 6) return launch_split_s2_inst<32, 6, ST, NP>(a, grid, smem, st);
+    if (bn == 64 && maxu == 5) return launch_split_s2_inst<64, 5, ST, NP>(a, grid, smem, st);
+    if (bn == 64 && maxu == 6) return launch_split_s2_inst<64, 6, ST, NP>(a, grid, smem, st);
     return hipErrorInvalidConfiguration;
+}
+hipError_t launch_split_s2(bool f16, int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    return f16 ? launch_split_s2_t<_Float16, 1>(bn, maxu, a, grid, smem, st) : launch_split_s2_t<float, 3>(bn, maxu, a, grid, smem, st);
+}
+
+void launch_stats_direct(bool f16, int B, int C, int HW, const float* x, const float* g, const float* be, float eps, float* sc, float* sh, hipStream_t st) {
+    if (f16) hipLaunchKernelGGL(stats_direct<_Float16>, dim3(B, C / 32), dim3(256), 0, st, reinterpret_cast<const _Float16*>(x), C, HW, g, be, eps, sc, sh);
+    else hipLaunchKernelGGL(stats_direct<float>, dim3(B, C / 32), dim3(256), 0, st, x, C, HW, g, be, eps, sc, sh);
 }
 
 // Split-K factor for a split-fp16 conv whose grid would leave most CUs idle (8x8 / 4x4 bottleneck levels).
@@ -553,6 +566,9 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
     const ts2d_arch_desc& a = e->arch;
     e->n_launched = 0;
     e->lastB = B; e->lastH = H; e->lastW = W; e->last_stream = st;
+    const bool f16 = e->precision == TS2D_PRECISION_F16;      // fp16 storage, one fp16 MFMA product, fp32 accumulate/statistics
+    e->last_f16 = f16;
+    if (f16 && !e->ops[0].first_direct) return fail(TS2D_ERR_INVALID, "fp16 mode needs <= 4 input channels");
     if (!e->ops[0].first_direct) {   // boundary layout change NCHW -> NHWC (channels zero-padded to 8); > 4 input channels only
         const long long total = (long long)B * H * W;
         TRY(prof_begin(e, "input.nhwc", st));
@@ -577,10 +593,12 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             const int kp = (op.cin + 1) / 2, nt = op.cout / 32, P = (g.PH * g.PW) << g.lgNIMG;
             const size_t smem = std::max((size_t)P * (2 * kp + 1) * sizeof(float), (size_t)4 * op.cout * 2 * sizeof(float));
             TRY(prof_begin(e, op.name, st));
-            if (nt == 1 && kp == 1) hipLaunchKernelGGL((conv3x3_first<1, 1>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa);
-            else if (nt == 1 && kp == 2) hipLaunchKernelGGL((conv3x3_first<1, 2>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa);
-            else if (nt == 2 && kp == 1) hipLaunchKernelGGL((conv3x3_first<2, 1>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa);
-            else if (nt == 2 && kp == 2) hipLaunchKernelGGL((conv3x3_first<2, 2>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa);
+#define TS2D_FIRST(NT_, KP_) do { if (f16) hipLaunchKernelGGL((conv3x3_first<NT_, KP_, _Float16>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa); \
+                                  else hipLaunchKernelGGL((conv3x3_first<NT_, KP_, float>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa); } while (0)
+            if (nt == 1 && kp == 1) TS2D_FIRST(1, 1);
+            else if (nt == 1 && kp == 2) TS2D_FIRST(1, 2);
+            else if (nt == 2 && kp == 1) TS2D_FIRST(2, 1);
+            else if (nt == 2 && kp == 2) TS2D_FIRST(2, 2);
             else return fail(TS2D_ERR_INVALID, "first block: unsupported Cout %d / Cin %d", op.cout, op.cin);
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
@@ -589,8 +607,7 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
                                    op.cout, B, H * W, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
             else
-                hipLaunchKernelGGL(stats_direct, dim3(B, op.cout / 32), dim3(256), 0, st, dst.data, op.cout, H * W,
-                                   wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+                launch_stats_direct(f16, B, op.cout, H * W, dst.data, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift, st);
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
             continue;
@@ -615,7 +632,8 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             const int bn = (ca.N % 64 == 0 && op.cout % 64 == 0) ? 64 : 32;
             ca.n_mtiles = g.n_mtiles; ca.n_ctiles = ca.N / bn; ca.PH = g.PH; ca.PW = g.PW; ca.slope = a.leaky_slope;
             const int P = (g.PH * g.PW) << g.lgNIMG;
-            const bool split = op.split_ok && e->precision == TS2D_PRECISION_F32_SPLIT_F16X3;
+            const bool split = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT;
+            if (f16 && !split) return fail(TS2D_ERR_INVALID, "op %s has no fp16 kernel (channel counts must be multiples of 16)", op.name.c_str());
             if (split && !conv) {
                 ca.n_ctiles = ca.N / 64;                       // N = 4 * Cout is a multiple of 128; each 32-column tile lies in one (a,b) tap
                 ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
@@ -623,7 +641,8 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 const size_t smem_t = (size_t)2 * Pt * kRec + (size_t)2 * 64 * kRec;
                 const int grid_t = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
                 TRY(prof_begin(e, op.name, st));
-                hipLaunchKernelGGL(convT2x2_f16x3<64>, dim3(grid_t), dim3(kBlock), smem_t, st, ca);
+                if (f16) hipLaunchKernelGGL((convT2x2_f16x3<64, _Float16, 1>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
+                else hipLaunchKernelGGL((convT2x2_f16x3<64, float, 3>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
                 continue;
@@ -645,10 +664,10 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             const int grid = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
             TRY(prof_begin(e, op.name, st));
             // warp-specialised persistent kernel: stride 1, tile inside one image, patch <= 384 pixels
-            const bool ws = split && stride == 1 && g.lgNIMG == 0 && P <= 384 && e->use_ws;
+            const bool ws = split && !f16 && stride == 1 && g.lgNIMG == 0 && P <= 384 && e->use_ws;
             hipError_t le;
             const size_t smem_pp = 2 * ((size_t)P * kRec + (size_t)9 * bn * kRec) + (size_t)2 * 4 * bn * 2 * sizeof(float);
-            const bool pp = split && stride == 1 && !ws && e->use_pp && smem_pp <= 160 * 1024;
+            const bool pp = split && !f16 && stride == 1 && !ws && e->use_pp && smem_pp <= 160 * 1024;
             if (pp) {      // ping-pong kernel: two pixel tiles per 512-thread workgroup in enforced anti-phase
                 const int n_pairs = (g.n_mtiles + 1) / 2;
                 le = launch_split_pp(bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, (n_pairs + 7) / 8 * 8 * ca.n_ctiles, smem_pp, st);
@@ -656,8 +675,8 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 const size_t smem_ws = 2 * ((size_t)P * kRec + (size_t)9 * bn * kRec) + (size_t)4 * bn * 2 * sizeof(float);
                 le = launch_split_ws(bn, ca, grid, std::min(grid, e->num_cus), smem_ws, st);
             } else if (split) {
-                le = stride == 1 ? launch_split(bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, grid, smem, st)
-                                 : launch_split_s2(bn, P <= 5 * kBlock ? 5 : 6, ca, grid, smem, st);
+                le = stride == 1 ? launch_split(f16, bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, grid, smem, st)
+                                 : launch_split_s2(f16, bn, P <= 5 * kBlock ? 5 : 6, ca, grid, smem, st);
             } else {
                 le = launch_conv(taps, stride, op.ck, bn, ca, grid, smem, st);
             }
@@ -667,14 +686,15 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 const int HW = Ht * Wt;
                 TRY(prof_begin(e, op.name + ".stats", st));
                 if (ksplit > 1) {
-                    hipLaunchKernelGGL(splitk_reduce_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, ksplit, ca.kslice_stride,
-                                       wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.data, dst.scale, dst.shift);
+                    if (f16) hipLaunchKernelGGL(splitk_reduce_stats<_Float16>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, ksplit, ca.kslice_stride,
+                                                wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, reinterpret_cast<_Float16*>(dst.data), dst.scale, dst.shift);
+                    else hipLaunchKernelGGL(splitk_reduce_stats<float>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, ksplit, ca.kslice_stride,
+                                            wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.data, dst.scale, dst.shift);
                 } else if (fused) {
                     hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
                                        op.cout, B, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 } else {
-                    hipLaunchKernelGGL(stats_direct, dim3(B, op.cout / 32), dim3(256), 0, st, dst.data, op.cout, HW,
-                                       wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+                    launch_stats_direct(f16, B, op.cout, HW, dst.data, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift, st);
                 }
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
@@ -689,12 +709,16 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             TRY(prof_begin(e, op.name, st));
             if (src.C == 32) {
                 static bool set32 = false;
-                if (!set32) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set32 = true; }
-                hipLaunchKernelGGL(head_1x1<32>, dim3(grid), dim3(256), smem, st, ha);
+                if (!set32) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<32, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<32, _Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set32 = true; }
+                if (f16) hipLaunchKernelGGL((head_1x1<32, _Float16>), dim3(grid), dim3(256), smem, st, ha);
+                else hipLaunchKernelGGL((head_1x1<32, float>), dim3(grid), dim3(256), smem, st, ha);
             } else {
                 static bool set64 = false;
-                if (!set64) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set64 = true; }
-                hipLaunchKernelGGL(head_1x1<64>, dim3(grid), dim3(256), smem, st, ha);
+                if (!set64) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<64, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<64, _Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set64 = true; }
+                if (f16) hipLaunchKernelGGL((head_1x1<64, _Float16>), dim3(grid), dim3(256), smem, st, ha);
+                else hipLaunchKernelGGL((head_1x1<64, float>), dim3(grid), dim3(256), smem, st, ha);
             }
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
@@ -762,7 +786,7 @@ int ts2d_engine_weight_buffer(ts2d_engine* e, void** dev_ptr, size_t* n_bytes) {
 
 int ts2d_engine_set_precision(ts2d_engine* e, int mode) {
     if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_precision: null engine");
-    if (mode != TS2D_PRECISION_F32_EXACT && mode != TS2D_PRECISION_F32_SPLIT_F16X3)
+    if (mode != TS2D_PRECISION_F32_EXACT && mode != TS2D_PRECISION_F32_SPLIT_F16X3 && mode != TS2D_PRECISION_F16)
         return fail(TS2D_ERR_INVALID, "unknown precision mode %d", mode);
     e->precision = mode;
     return TS2D_OK;
@@ -904,7 +928,13 @@ int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->last_stream ? e->last_stream : e->stream));
     std::vector<float> raw(n), sc, sh;
-    HIP_TRY(hipMemcpy(raw.data(), t.data, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (e->last_f16) {
+        std::vector<uint16_t> rh(n);
+        HIP_TRY(hipMemcpy(rh.data(), t.data, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) raw[i] = f16_to_f32(rh[i]);
+    } else {
+        HIP_TRY(hipMemcpy(raw.data(), t.data, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
     if (t.normed) {
         sc.resize((size_t)B * C); sh.resize((size_t)B * C);
         HIP_TRY(hipMemcpy(sc.data(), t.scale, sc.size() * sizeof(float), hipMemcpyDeviceToHost));

@@ -296,14 +296,15 @@ __global__ __launch_bounds__(256) void finalize_stats(const float* __restrict__ 
 }
 
 // (b) directly from the raw NHWC tensor (small layers whose tile spans several images): block per (n, 32 channels).
-__global__ __launch_bounds__(256) void stats_direct(const float* __restrict__ x, int C, int HW,
+template <typename ST>
+__global__ __launch_bounds__(256) void stats_direct(const ST* __restrict__ x, int C, int HW,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float eps, float* __restrict__ scale, float* __restrict__ shift) {
     const int n = blockIdx.x, c = blockIdx.y * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
     __shared__ double rs[8][32], rq[8][32];
     double s = 0.0, q = 0.0;
     for (int p = pl; p < HW; p += 8) {
-        const double v = x[((size_t)n * HW + p) * C + c];
+        const double v = (double)(float)x[((size_t)n * HW + p) * C + c];
         s += v; q += v * v;
     }
     rs[pl][threadIdx.x & 31] = s; rq[pl][threadIdx.x & 31] = q;
@@ -322,10 +323,11 @@ __global__ __launch_bounds__(256) void stats_direct(const float* __restrict__ x,
 
 // (c) split-K epilogue for the tiny bottleneck layers: fixed-order sum of the S partial outputs + bias -> raw output,
 // and the InstanceNorm scale/shift of that output in the same pass.  Grid (B, C/32), 256 threads = 8 pixel lanes x 32 ch.
+template <typename ST>
 __global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restrict__ partial, int S, long long slice_stride,
                                                           const float* __restrict__ bias, int C, int HW,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float eps, float* __restrict__ dst, float* __restrict__ scale,
+                                                          float eps, ST* __restrict__ dst, float* __restrict__ scale,
                                                           float* __restrict__ shift) {
     const int n = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, pl = threadIdx.x >> 5;
     __shared__ double rs[8][32], rq[8][32];
@@ -336,7 +338,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restri
         float v = 0.f;
         for (int k = 0; k < S; ++k) v += partial[(size_t)k * slice_stride + o];
         v += b;
-        dst[o] = v;
+        dst[o] = (ST)v;
+        v = (float)(ST)v;
         s += (double)v; q += (double)v * (double)v;
     }
     rs[pl][cl] = s; rq[pl][cl] = q;
@@ -386,7 +389,7 @@ struct HeadArgs {
     float slope;
 };
 
-template <int C>
+template <int C, typename ST = float>
 __global__ __launch_bounds__(256) void head_1x1(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sx = smem;                       // [256][C+1]
@@ -403,7 +406,13 @@ __global__ __launch_bounds__(256) void head_1x1(const HeadArgs a) {
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p < a.total) {
             const long long n = p / a.HW;
-            v = *reinterpret_cast<const f32x4*>(a.src + p * C + c4);
+            if (sizeof(ST) == 4) v = *reinterpret_cast<const f32x4*>(a.src + p * C + c4);
+            else {
+                typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                const half4_t hv = *reinterpret_cast<const half4_t*>(reinterpret_cast<const _Float16*>(a.src) + p * C + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (float)hv[e];
+            }
             const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.sc + n * C + c4);
             const f32x4 s2 = *reinterpret_cast<const f32x4*>(a.sh + n * C + c4);
             v = v * s1 + s2;

@@ -17,6 +17,35 @@ namespace ts2d {
 // 16 consecutive records) touches 16 distinct slots: conflict-free.
 constexpr int kRec = 80;
 
+// Activation STORAGE type ST: float (the fp32-parity modes) or _Float16 ("mixed fp16": fp16 storage, one fp16 MFMA product,
+// fp32 accumulation and statistics - BASELINE configs 3/5).  NP = MFMA products per MAC: 3 (hi/lo split) or 1.
+template <typename ST> struct Raw8;
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void zero() { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+    __device__ __forceinline__ void load(const void* base, size_t off) {
+        const float* p = reinterpret_cast<const float*>(base) + off;
+        a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    __device__ __forceinline__ void get(f32x4& va, f32x4& vb) const { va = a; vb = b; }
+};
+template <> struct Raw8<_Float16> {
+    half8 h;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (_Float16)0.f;
+    }
+    __device__ __forceinline__ void load(const void* base, size_t off) {
+        h = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(base) + off);
+    }
+    __device__ __forceinline__ void get(f32x4& va, f32x4& vb) const {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { va[e] = (float)h[e]; vb[e] = (float)h[e + 4]; }
+    }
+};
+template <typename ST> __device__ __forceinline__ float round_act(float v) { return (float)(ST)v; }
+template <typename ST> __device__ __forceinline__ void store_act(void* base, size_t off, float v) { reinterpret_cast<ST*>(base)[off] = (ST)v; }
+
 
 // Shared epilogue: undo the weight pre-scale, add bias, store the raw NHWC output, per-tile InstanceNorm partials.
 // C/D map of the 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).
@@ -38,7 +67,7 @@ __device__ __forceinline__ void stagger_start(const ConvArgs& a, unsigned char* 
     }
 }
 
-template <int BN>
+template <int BN, typename ST = float>
 __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t)[2][BN / 32], unsigned char* smem8,
                                                int n0col, int nimg0, int ty0, int tx0, int tpi, int tin) {
     constexpr int NT = BN / 32;
@@ -52,7 +81,6 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
         const float bv = a.ksplit > 1 ? 0.f : a.bias[co];      // split-K partials: bias is added by splitk_reduce_stats
-        float* const obase = a.dst + (size_t)blockIdx.y * a.kslice_stride;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -62,8 +90,10 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
                 const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
                 const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
                 if (il < NIMG && n < a.B && oy < a.Ht && ox < a.Wt) {
-                    const float v = acc_t[mt][nt][i] * oscale + bv;
-                    obase[((size_t)(n * a.Ht + oy) * a.Wt + ox) * a.Cout + co] = v;
+                    float v = acc_t[mt][nt][i] * oscale + bv;
+                    const size_t o = ((size_t)(n * a.Ht + oy) * a.Wt + ox) * a.Cout + co;
+                    if (a.ksplit > 1) a.dst[(size_t)blockIdx.y * a.kslice_stride + o] = v;          // fp32 partial
+                    else { store_act<ST>(a.dst, o, v); v = round_act<ST>(v); }                      // statistics of what is stored
                     st_s[nt] += v; st_q[nt] += v * v;
                 }
             }
@@ -90,7 +120,7 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
 }
 
 // PF = chunks of raw patch data kept in flight in registers (2 for the HBM-bound small-Cin layers: more bytes in flight).
-template <int BN, int MAXU, int PF = 1>
+template <int BN, int MAXU, int PF = 1, typename ST = float, int NP = 3>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
     constexpr int NT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
@@ -157,24 +187,20 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
             for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
 
     const int nchunks = (a.C0 + a.C1) / 16;
-    f32x4 pv[PF][MAXU][2];             // prefetched raw patch values of the next PF chunks (in flight during the MFMAs)
+    Raw8<ST> pv[PF][MAXU];             // prefetched raw patch values of the next PF chunks (in flight during the MFMAs)
 
     auto chunk_src = [&](int ch, const float*& src, const float*& sc, const float*& sh, int& C, int& cb) {
         cb = ch * 16;
         if (cb < a.C0) { src = a.src0; sc = a.sc0; sh = a.sh0; C = a.C0; }
         else { cb -= a.C0; src = a.src1; sc = a.sc1; sh = a.sh1; C = a.C1; }
     };
-    auto prefetch = [&](int ch, f32x4 (&pq)[MAXU][2]) {
+    auto prefetch = [&](int ch, Raw8<ST> (&pq)[MAXU]) {
         const float* src; const float* sc; const float* sh; int C, cb;
         chunk_src(ch, src, sc, sh, C, cb);
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
-            pq[it][0] = f32x4{0.f, 0.f, 0.f, 0.f}; pq[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (goff[it] >= 0) {
-                const float* p = src + (size_t)goff[it] * C + cb + oct;
-                pq[it][0] = *reinterpret_cast<const f32x4*>(p);
-                pq[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
-            }
+            pq[it].zero();
+            if (goff[it] >= 0) pq[it].load(src, (size_t)goff[it] * C + cb + oct);
         }
     };
 
@@ -203,7 +229,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
             for (int it = 0; it < MAXU; ++it) {
                 const int u = tid + it * kBlock;
                 if (u < total) {
-                    f32x4 va = pv[s][it][0], vb = pv[s][it][1];
+                    f32x4 va, vb;
+                    pv[s][it].get(va, vb);
                     if (sc != nullptr && goff[it] >= 0) {
                         if (a.lgNIMG != 0) {
                             const size_t o = (size_t)(nimg0 + (int)((imgbits >> (4 * it)) & 15)) * C + cb + oct;
@@ -222,11 +249,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
                     for (int e = 0; e < 4; ++e) {
                         const _Float16 ha = (_Float16)va[e], hb = (_Float16)vb[e];
                         hi[e] = ha; hi[e + 4] = hb;
-                        lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb);
+                        if (NP == 3) { lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb); }
                     }
                     unsigned char* d = sA + (u >> 1) * kRec + (u & 1) * 16;
                     *reinterpret_cast<half8*>(d) = hi;
-                    *reinterpret_cast<half8*>(d + 32) = lo;
+                    if (NP == 3) *reinterpret_cast<half8*>(d + 32) = lo;
                 }
             }
         }
@@ -237,7 +264,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
 #pragma unroll
             for (int it = 0; it < (WU + kBlock - 1) / kBlock; ++it) {
                 const int idx = tid + it * kBlock;
-                if (idx < WU) {
+                if (idx < WU && (NP == 3 || (idx & 2) == 0)) {
                     const int tc = idx >> 2, part = idx & 3;
                     const int tap = tc / BN, col = tc - tap * BN;
                     *reinterpret_cast<uint4*>(sB + tc * kRec + part * 16) = wsrc[((size_t)tap * a.N + col) * 4 + part];
@@ -261,23 +288,23 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
             // fragment reads in first-use order (lo*hi products first): the MFMAs can start after two reads have landed
             half8 ah[2], al[2], bh[NT], bl[NT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff + 32);
+            for (int mt = 0; mt < 2; ++mt) if (NP == 3) al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff + 32);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bh[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) ah[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bl[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase + 32);
+            for (int nt = 0; nt < NT; ++nt) if (NP == 3) bl[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase + 32);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+                    { if (NP == 3) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0); }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0);
+                    { if (NP == 3) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0); }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -292,7 +319,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
     }
     }
 
-    split_epilogue<BN>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
+    split_epilogue<BN, ST>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -304,7 +331,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kRec8 = 48;
 
-template <int BN, int MAXU>
+template <int BN, int MAXU, typename ST = float, int NP = 3>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
     constexpr int NT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
@@ -375,16 +402,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
             for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
 
     const int nchunks = a.C0 / 8;      // the strided conv never reads a concat
-    f32x4 pv[MAXU][2];
+    Raw8<ST> pv[MAXU];
     auto prefetch = [&](int ch) {
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
-            pv[it][0] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (goff[it] >= 0) {
-                const float* p = a.src0 + (size_t)goff[it] * a.C0 + ch * 8;
-                pv[it][0] = *reinterpret_cast<const f32x4*>(p);
-                pv[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
-            }
+            pv[it].zero();
+            if (goff[it] >= 0) pv[it].load(a.src0, (size_t)goff[it] * a.C0 + ch * 8);
         }
     };
 
@@ -405,7 +428,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
             for (int it = 0; it < MAXU; ++it) {
                 const int u = tid + it * kBlock;
                 if (u < P) {
-                    f32x4 va = pv[it][0], vb = pv[it][1];
+                    f32x4 va, vb;
+                    pv[it].get(va, vb);
                     if (a.sc0 != nullptr && goff[it] >= 0) {
                         if (a.lgNIMG != 0) {
                             const size_t o = (size_t)(nimg0 + (int)((imgbits >> (4 * it)) & 15)) * a.C0 + cb;
@@ -424,10 +448,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
                     for (int e = 0; e < 4; ++e) {
                         const _Float16 ha = (_Float16)va[e], hb = (_Float16)vb[e];
                         hi[e] = ha; hi[e + 4] = hb;
-                        lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb);
+                        if (NP == 3) { lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb); }
                     }
                     *reinterpret_cast<half8*>(sA + lrec[it]) = hi;
-                    *reinterpret_cast<half8*>(sA + lrec[it] + 16) = lo;
+                    if (NP == 3) *reinterpret_cast<half8*>(sA + lrec[it] + 16) = lo;
                 }
             }
         }
@@ -437,7 +461,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
 #pragma unroll
             for (int it = 0; it < (WU + kBlock - 1) / kBlock; ++it) {
                 const int idx = tid + it * kBlock;
-                if (idx < WU) {
+                if (idx < WU && (NP == 3 || (idx & 2) == 0)) {
                     const int tc = idx >> 2, part = idx & 3;
                     const int ks = tc / BN, col = tc - ks * BN;
                     *reinterpret_cast<uint4*>(sB + tc * kRec + part * 16) = wsrc[((size_t)ks * a.N + col) * 4 + part];
@@ -460,23 +484,23 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 ah[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s]);
-                al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s] + 16);
+                if (NP == 3) al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s] + 16);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 bh[nt] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase);
-                bl[nt] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase + 32);
+                if (NP == 3) bl[nt] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase + 32);
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+                    { if (NP == 3) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0); }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0);
+                    { if (NP == 3) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0); }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -488,7 +512,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
     }
-    split_epilogue<BN>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
+    split_epilogue<BN, ST>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
 }
 
 }  // namespace ts2d

@@ -8,7 +8,7 @@
 
 namespace ts2d {
 
-template <int BN>
+template <int BN, typename ST = float, int NP = 3>
 __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
     constexpr int NT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
@@ -65,16 +65,12 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
     const int nchunks = a.C0 / 32;
-    f32x4 pv[4][2];
+    Raw8<ST> pv[4];
     auto prefetch = [&](int ch) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            pv[it][0] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (goff[it] >= 0) {
-                const float* p = a.src0 + (size_t)goff[it] * a.C0 + ch * 32 + oct;
-                pv[it][0] = *reinterpret_cast<const f32x4*>(p);
-                pv[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
-            }
+            pv[it].zero();
+            if (goff[it] >= 0) pv[it].load(a.src0, (size_t)goff[it] * a.C0 + ch * 32 + oct);
         }
     };
 
@@ -86,7 +82,8 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
             const int u = tid + it * kBlock;
             const int m = u >> 2;
             if (m < P) {
-                f32x4 va = pv[it][0], vb = pv[it][1];
+                f32x4 va, vb;
+                pv[it].get(va, vb);
                 if (a.sc0 != nullptr && goff[it] >= 0) {
                     const size_t o = (size_t)nimg[it] * a.C0 + ch * 32 + oct;
                     const f32x4 s1a = *reinterpret_cast<const f32x4*>(a.sc0 + o), s1b = *reinterpret_cast<const f32x4*>(a.sc0 + o + 4);
@@ -103,12 +100,12 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     const _Float16 ha = (_Float16)va[e], hb = (_Float16)vb[e];
                     hi[e] = ha; hi[e + 4] = hb;
-                    lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb);
+                    if (NP == 3) { lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb); }
                 }
                 // octet o8 = u & 3: k-step kk = o8 >> 1, half of the 16-channel record = o8 & 1
                 unsigned char* d = sA + (((u & 3) >> 1) * P + m) * kRec + (u & 1) * 16;
                 *reinterpret_cast<half8*>(d) = hi;
-                *reinterpret_cast<half8*>(d + 32) = lo;
+                if (NP == 3) *reinterpret_cast<half8*>(d + 32) = lo;
             }
         }
         {
@@ -117,7 +114,7 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
 #pragma unroll
             for (int it = 0; it < (WU + kBlock - 1) / kBlock; ++it) {
                 const int idx = tid + it * kBlock;
-                if (idx < WU) {
+                if (idx < WU && (NP == 3 || (idx & 2) == 0)) {
                     const int tc = idx >> 2, part = idx & 3;
                     const int kk = tc / BN, col = tc - kk * BN;
                     *reinterpret_cast<uint4*>(sB + tc * kRec + part * 16) = wsrc[((size_t)kk * a.N + col) * 4 + part];
@@ -132,23 +129,23 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 ah[mt] = *reinterpret_cast<const half8*>(sA + kk * P * kRec + abase[mt]);
-                al[mt] = *reinterpret_cast<const half8*>(sA + kk * P * kRec + abase[mt] + 32);
+                if (NP == 3) al[mt] = *reinterpret_cast<const half8*>(sA + kk * P * kRec + abase[mt] + 32);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 bh[nt] = *reinterpret_cast<const half8*>(sB + (kk * BN + nt * 32) * kRec + bbase);
-                bl[nt] = *reinterpret_cast<const half8*>(sB + (kk * BN + nt * 32) * kRec + bbase + 32);
+                if (NP == 3) bl[nt] = *reinterpret_cast<const half8*>(sB + (kk * BN + nt * 32) * kRec + bbase + 32);
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    { if (NP == 3) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0); }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    { if (NP == 3) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0); }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -173,8 +170,8 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
                 const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
                 const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
                 if (il < NIMG && n < a.B && oy < a.Ht && ox < a.Wt)
-                    a.dst[((size_t)(n * 2 * a.Ht + 2 * oy + oa) * (2 * a.Wt) + 2 * ox + ob) * a.Cout + co] =
-                        acc[mt][nt][i] * oscale + bv;
+                    store_act<ST>(a.dst, ((size_t)(n * 2 * a.Ht + 2 * oy + oa) * (2 * a.Wt) + 2 * ox + ob) * a.Cout + co,
+                                  acc[mt][nt][i] * oscale + bv);
             }
         }
     }

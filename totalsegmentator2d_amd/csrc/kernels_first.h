@@ -4,7 +4,7 @@
 // (k = the two channels), the patch is read straight from the NCHW boundary tensor, and the weights live in registers
 // (one float per lane per (tap, pair, column tile)).  The network input is not normalised, so there is no prologue math.
 #pragma once
-#include "kernels.h"
+#include "kernels_f16x3.h"
 
 namespace ts2d {
 
@@ -18,7 +18,7 @@ struct FirstArgs {
     int lgTH, lgTW, lgNIMG, tiles_x, tiles_y, n_mtiles, PH, PW;
 };
 
-template <int NT, int KP>      // NT = Cout / 32 column tiles, KP = ceil(C / 2) channel pairs
+template <int NT, int KP, typename ST = float>      // NT = Cout / 32 column tiles, KP = ceil(C / 2) channel pairs, ST = output storage
 __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
     constexpr int CP = 2 * KP + 1;               // floats per patch pixel (+1 pad: conflict-free ds_read_b32)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -103,8 +103,9 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
                 const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
                 const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
                 if (il < NIMG && n < a.B && oy < a.H && ox < a.W) {
-                    const float v = acc[mt][nt][i] + bv;
-                    a.dst[((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + co] = v;
+                    float v = acc[mt][nt][i] + bv;
+                    store_act<ST>(a.dst, ((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + co, v);
+                    v = round_act<ST>(v);
                     ss += v; qq += v * v;
                 }
             }

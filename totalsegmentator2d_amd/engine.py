@@ -83,8 +83,9 @@ class Engine:
         _lib.check(self.lib.ts2d_engine_weights_ready(self._h), 'ts2d_engine_weights_ready')
 
     def set_precision(self, mode):
-        """'exact' (fp32 MFMA) or 'split' (fp16 hi/lo x3 MFMA, fp32-equivalent accuracy; the default)."""
-        m = {'exact': _lib.PRECISION_F32_EXACT, 'split': _lib.PRECISION_F32_SPLIT_F16X3}.get(mode, mode)
+        """'exact' (fp32 MFMA), 'split' (fp16 hi/lo x3 MFMA, fp32-equivalent accuracy; the default) or 'f16' (fp16 storage,
+        one fp16 MFMA product, fp32 accumulate/statistics: BASELINE configs 3/5, outside the fp32 parity tolerance)."""
+        m = {'exact': _lib.PRECISION_F32_EXACT, 'split': _lib.PRECISION_F32_SPLIT_F16X3, 'f16': _lib.PRECISION_F16}.get(mode, mode)
         _lib.check(self.lib.ts2d_engine_set_precision(self._h, int(m)), 'ts2d_engine_set_precision')
 
     # ------------------------------------------------------------------ forward
