@@ -217,6 +217,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
         const float* src; const float* sc; const float* sh; int C, cb;
         chunk_src(ch, src, sc, sh, C, cb);
         __syncthreads();   // the previous chunk's MFMA reads of LDS are done
+        // ---- weights of this chunk (L2-resident): issue the loads FIRST, their latency hides behind the patch conversion below.
+        //      Named registers (an array was demoted to scratch by the compiler).
+        constexpr int WU = 9 * BN * 4, WIT = (WU + kBlock - 1) / kBlock;
+        const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * 9 * a.N + n0col) * 4;
+        uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8;
+#define TS2D_WLOAD(K, R) { const int idx = tid + K * kBlock; if (K < WIT && idx < WU && (NP == 3 || (idx & 2) == 0)) { \
+            const int tc = idx >> 2, part = idx & 3; const int tap = tc / BN, col = tc - tap * BN; R = wsrc[((size_t)tap * a.N + col) * 4 + part]; } }
+        TS2D_WLOAD(0, w0) TS2D_WLOAD(1, w1) TS2D_WLOAD(2, w2) TS2D_WLOAD(3, w3) TS2D_WLOAD(4, w4)
+        TS2D_WLOAD(5, w5) TS2D_WLOAD(6, w6) TS2D_WLOAD(7, w7) TS2D_WLOAD(8, w8)
+#undef TS2D_WLOAD
         // ---- patch: normalise + LeakyReLU, split into fp16 hi/lo, write the LDS records
         {
             f32x4 s1a = f32x4{1.f, 1.f, 1.f, 1.f}, s1b = s1a, s2a = f32x4{0.f, 0.f, 0.f, 0.f}, s2b = s2a;
@@ -257,20 +267,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
                 }
             }
         }
-        // ---- weights of this chunk, columns [n0col, n0col+BN): global [chunk][tap][N][hi16|lo16] -> LDS records
-        {
-            constexpr int WU = 9 * BN * 4;
-            const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * 9 * a.N + n0col) * 4;
-#pragma unroll
-            for (int it = 0; it < (WU + kBlock - 1) / kBlock; ++it) {
-                const int idx = tid + it * kBlock;
-                if (idx < WU && (NP == 3 || (idx & 2) == 0)) {
-                    const int tc = idx >> 2, part = idx & 3;
-                    const int tap = tc / BN, col = tc - tap * BN;
-                    *reinterpret_cast<uint4*>(sB + tc * kRec + part * 16) = wsrc[((size_t)tap * a.N + col) * 4 + part];
-                }
-            }
-        }
+        // ---- weight registers -> LDS records [tap][col][hi16 | lo16 | pad]
+#define TS2D_WSTORE(K, R) { const int idx = tid + K * kBlock; if (K < WIT && idx < WU && (NP == 3 || (idx & 2) == 0)) \
+            *reinterpret_cast<uint4*>(sB + (idx >> 2) * kRec + (idx & 3) * 16) = R; }
+        TS2D_WSTORE(0, w0) TS2D_WSTORE(1, w1) TS2D_WSTORE(2, w2) TS2D_WSTORE(3, w3) TS2D_WSTORE(4, w4)
+        TS2D_WSTORE(5, w5) TS2D_WSTORE(6, w6) TS2D_WSTORE(7, w7) TS2D_WSTORE(8, w8)
+#undef TS2D_WSTORE
         __syncthreads();
         if (ch + PF < kend) prefetch(ch + PF, pv[s]);      // HBM latency hides behind the MFMA phases
 
