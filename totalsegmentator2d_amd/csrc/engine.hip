@@ -85,7 +85,6 @@ struct ts2d_engine {
                                   // slower than two independent 256-thread workgroups per CU in round 1
     int num_cus = 256;
     bool use_pp = false;          // ping-pong split kernel: opt-in experiment (TS2D_PP=1); measured slower in round 1
-    int stagger = 3;              // start offset between co-resident workgroups, units of ~1024 cycles (TS2D_STAGGER)
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
     float* d_part = nullptr;
@@ -653,7 +652,6 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 smem = stride == 1 ? (size_t)P * kRec + (size_t)9 * bn * kRec : (size_t)P * kRec8 + (size_t)5 * bn * kRec;
                 smem = std::max(smem, (size_t)4 * bn * 2 * sizeof(float));
                 ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
-                ca.stagger = e->stagger;
             }
             const int ksplit = (split && !e->use_ws && !e->use_pp) ? choose_ksplit(e, op, B, H, W) : 1;
             if (ksplit > 1) {
@@ -748,7 +746,6 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
-        if (getenv("TS2D_STAGGER")) e->stagger = atoi(getenv("TS2D_STAGGER"));
         if (getenv("TS2D_PP")) e->use_pp = getenv("TS2D_PP")[0] == '1';
         const char* ws = getenv("TS2D_WS");
         e->use_ws = ws && ws[0] == '1';

@@ -42,7 +42,6 @@ struct ConvArgs {
     const void* wph;      // split-fp16 packed weights [chunk][tap][N][16 hi | 16 lo] (f16x3 kernel only)
     int ksplit;           // split-K: blockIdx.y = K slice; slice s writes un-biased partials to dst + s * kslice_stride
     long long kslice_stride;
-    int stagger;          // first-round workgroups in SIMD wave slot k start k * stagger * ~1024 cycles late (0 = off)
     const float* oscale;  // device scalar: 1 / (power-of-two weight pre-scale); lives in the weight arena so that it
                           // travels with the multi-GPU weight broadcast (f16x3 kernel only)
 };

@@ -50,23 +50,6 @@ template <typename ST> __device__ __forceinline__ void store_act(void* base, siz
 // Shared epilogue: undo the weight pre-scale, add bias, store the raw NHWC output, per-tile InstanceNorm partials.
 // C/D map of the 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).
 
-// De-synchronise the workgroups that share a CU.  Identical workgroups dispatched together run in lockstep: their MFMA
-// phases collide and their staging phases collide, so nothing overlaps (measured: time = MFMA + staging).  Delaying the
-// workgroup that sits in SIMD wave slot k by k * stagger at kernel start makes one workgroup's MFMA phase coincide
-// with the other's staging phase, and equal-length workgroups keep that offset for the rest of the launch
-// (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Only first-round workgroups are delayed; later ones start
-// whenever a slot frees and inherit the offset.
-__device__ __forceinline__ void stagger_start(const ConvArgs& a, unsigned char* smem8) {
-    if (a.stagger > 0 && blockIdx.x < 1024) {
-        unsigned* flag = reinterpret_cast<unsigned*>(smem8);
-        if (threadIdx.x == 0) *flag = __builtin_amdgcn_s_getreg(6148) & 15u;     // HW_REG_HW_ID[3:0] = wave slot on its SIMD
-        __syncthreads();
-        const unsigned slot = *flag;
-        __syncthreads();
-        for (unsigned k = 0; k < slot * (unsigned)a.stagger; ++k) __builtin_amdgcn_s_sleep(16);
-    }
-}
-
 template <int BN, typename ST = float>
 __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t)[2][BN / 32], unsigned char* smem8,
                                                int n0col, int nimg0, int ty0, int tx0, int tpi, int tin) {
@@ -146,7 +129,6 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
     const int P = PHW << a.lgNIMG;
     unsigned char* sA = smem8;
     unsigned char* sB = smem8 + P * kRec;
-    stagger_start(a, smem8);
 
     // ---- staging plan: unit u = (patch pixel u >> 1, channel octet u & 1); divisions by float reciprocal (exact here)
     int goff[MAXU];
@@ -284,6 +266,50 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc_c[mt][nt][i] = 0.f;
         __builtin_amdgcn_s_setprio(1);     // the MFMA phase outranks the co-resident workgroup's staging phase
+        constexpr bool PIPE = (BN == 64 && MAXU == 3);     // register budget: 256 VGPRs at 2 workgroups/CU; BN = 32 must stay <= 168 for 3
+        if constexpr (PIPE) {
+        // Software-pipelined over the 9 taps: the fragments of tap t+1 are read (double-buffered registers) while the MFMAs of
+        // tap t run; the sched_barrier keeps the read-ahead at exactly one tap.  Probe (scripts/probes/mfma_phase_probe.hip):
+        // 5.6k instead of 17.9k cycles per chunk for the bare loop at 2 workgroups/CU.
+        half8 fa[2][2][2], fb[2][NT][2];            // [buffer][tile][hi, lo]
+        auto load_frags = [&](int buf, int tap) {
+            const int toff = ((tap / 3) * a.PW + (tap % 3)) * kRec;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                fa[buf][mt][0] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff);
+                if (NP == 3) fa[buf][mt][1] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff + 32);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                fb[buf][nt][0] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase);
+                if (NP == 3) fb[buf][nt][1] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase + 32);
+            }
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cur = tap & 1;
+            if (tap + 1 < 9) load_frags(cur ^ 1, tap + 1);
+            if (NP == 3) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][1], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][1], acc_c[mt][nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        } else {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = ((tap / 3) * a.PW + (tap % 3)) * kRec;
@@ -312,6 +338,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+        }
         }
         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -359,7 +386,6 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
     const int P = PHW << a.lgNIMG;
     unsigned char* sA = smem8;
     unsigned char* sB = smem8 + P * kRec8;
-    stagger_start(a, smem8);
 
     int goff[MAXU], lrec[MAXU];
     unsigned long long imgbits = 0;

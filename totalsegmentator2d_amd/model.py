@@ -89,6 +89,7 @@ class HIPModel:
         kw['use_mirroring'] = bool(p.get('nnu.predict.augment', True))        # reference default: True (wrapper.py:65)
         kw['verbose'] = bool(p.get('nnu.verbose', False))
         kw['device'] = self._config.get('device')
+        kw['precision'] = p.get('hip.precision', self._config.get('precision', 'split'))     # engine arithmetic mode (include/ts2d_engine.h)
         if self._config.get('network') is not None:          # test hook: host-logic tests without a GPU (predictor.py)
             kw['network'] = self._config['network']
         pred = HIPnnUNetPredictor(**kw)

@@ -41,7 +41,7 @@ class _Device:
 class HIPnnUNetPredictor:
     def __init__(self, tile_step_size: float = 0.5, use_gaussian: bool = True, use_mirroring: bool = True,
                  perform_everything_on_device: bool = True, device=None, verbose: bool = False,
-                 verbose_preprocessing: bool = False, allow_tqdm: bool = True, max_batch: int = 64,
+                 verbose_preprocessing: bool = False, allow_tqdm: bool = True, max_batch: int = 64, precision: str = 'split',
                  network: Optional[Callable[[np.ndarray], np.ndarray]] = None):
         """``network``: test hook - a callable [B,C,h,w] -> [B,K,h,w] used INSTEAD of creating HIP engines (host-logic
         unit tests on machines without a GPU).  The product path never passes it."""
@@ -53,6 +53,9 @@ class HIPnnUNetPredictor:
         self.verbose_preprocessing = verbose_preprocessing
         self.allow_tqdm = allow_tqdm
         self.max_batch = int(max_batch)
+        if precision not in ('split', 'exact', 'f16'):
+            raise ValueError("precision must be 'split' (fp32-equivalent, default), 'exact' (fp32 MFMA) or 'f16' (like the reference's CUDA autocast path)")
+        self.precision = precision
         idx = 0
         if device is not None:
             idx = getattr(device, 'index', device)
@@ -130,6 +133,8 @@ class HIPnnUNetPredictor:
         for e in self.engines:
             e.close()
         self.engines = [Engine(self.arch, blob, self.device.index) for blob in self.list_of_parameters]
+        for e in self.engines:
+            e.set_precision(self.precision)
 
     def close(self):
         for e in self.engines:
