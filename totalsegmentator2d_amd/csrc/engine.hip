@@ -276,9 +276,9 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                         const float v = w[((size_t)co * ct + ci) * 9 + tap] * wscale;
                         const uint16_t hi = f32_to_f16(v);
                         const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
-                        if (op.stride == 1) {
-                            const int chunk = ci / 16, cc = ci % 16;
-                            uint16_t* rec = d + (((size_t)chunk * 9 + tap) * co_n + co) * 32;
+                        if (op.stride == 1) {   // [chunk16][column tile][tap][column in tile][16 hi | 16 lo]: one contiguous block per (chunk, tile)
+                            const int chunk = ci / 16, cc = ci % 16, bn = co_n % 64 == 0 ? 64 : 32;
+                            uint16_t* rec = d + ((((size_t)chunk * (co_n / bn) + co / bn) * 9 + tap) * bn + co % bn) * 32;
                             rec[cc] = hi; rec[16 + cc] = lo;
                         } else {       // K packed as 8 channels x 2 taps: k = 8 * (tap & 1) + (ci % 8) of k-step tap / 2
                             const int chunk = ci / 8, cc = (tap & 1) * 8 + ci % 8;

@@ -202,10 +202,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
         // ---- weights of this chunk (L2-resident): issue the loads FIRST, their latency hides behind the patch conversion below.
         //      Named registers (an array was demoted to scratch by the compiler).
         constexpr int WU = 9 * BN * 4, WIT = (WU + kBlock - 1) / kBlock;
-        const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * 9 * a.N + n0col) * 4;
+        // the weight image holds one contiguous [tap][column][16 hi | 16 lo] block per (chunk, column tile): no index arithmetic
+        const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * a.n_ctiles + ctile) * (9 * BN * 4);
         uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8;
-#define TS2D_WLOAD(K, R) { const int idx = tid + K * kBlock; if (K < WIT && idx < WU && (NP == 3 || (idx & 2) == 0)) { \
-            const int tc = idx >> 2, part = idx & 3; const int tap = tc / BN, col = tc - tap * BN; R = wsrc[((size_t)tap * a.N + col) * 4 + part]; } }
+#define TS2D_WLOAD(K, R) { const int idx = tid + K * kBlock; if (K < WIT && idx < WU && (NP == 3 || (idx & 2) == 0)) R = wsrc[idx]; }
         TS2D_WLOAD(0, w0) TS2D_WLOAD(1, w1) TS2D_WLOAD(2, w2) TS2D_WLOAD(3, w3) TS2D_WLOAD(4, w4)
         TS2D_WLOAD(5, w5) TS2D_WLOAD(6, w6) TS2D_WLOAD(7, w7) TS2D_WLOAD(8, w8)
 #undef TS2D_WLOAD

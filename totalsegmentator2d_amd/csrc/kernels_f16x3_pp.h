@@ -150,14 +150,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3_pp(const ConvArgs a) {
                     }
                 }
                 constexpr int WU = 9 * BN * 4;
-                const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * 9 * a.N + n0col) * 4;
+                const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * a.n_ctiles + ctile) * (9 * BN * 4);
 #pragma unroll
                 for (int it = 0; it < (WU + kBlock - 1) / kBlock; ++it) {
                     const int idx = tid + it * kBlock;
                     if (idx < WU) {
-                        const int tc = idx >> 2, part = idx & 3;
-                        const int tap = tc / BN, col = tc - tap * BN;
-                        *reinterpret_cast<uint4*>(sB + tc * kRec + part * 16) = wsrc[((size_t)tap * a.N + col) * 4 + part];
+                        *reinterpret_cast<uint4*>(sB + (idx >> 2) * kRec + (idx & 3) * 16) = wsrc[idx];
                     }
                 }
             } else {

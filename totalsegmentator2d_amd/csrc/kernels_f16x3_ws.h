@@ -132,14 +132,12 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv3x3_f16x3_ws(const ConvArgs
                 }
             }
             if (stage_w) {                  // weights of this chunk (L2-resident): global -> LDS records
-                const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch_w * 9 * a.N + n0col_w) * 4;
+                const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch_w * a.n_ctiles + n0col_w / BN) * (9 * BN * 4);
 #pragma unroll
                 for (int it = 0; it < (WU + 255) / 256; ++it) {
                     const int idx = ptid + it * 256;
                     if (idx < WU) {
-                        const int tc = idx >> 2, part = idx & 3;
-                        const int tap = tc / BN, col = tc - tap * BN;
-                        *reinterpret_cast<uint4*>(sB + tc * kRec + part * 16) = wsrc[((size_t)tap * a.N + col) * 4 + part];
+                        *reinterpret_cast<uint4*>(sB + (idx >> 2) * kRec + (idx & 3) * 16) = wsrc[idx];
                     }
                 }
             }
