@@ -114,6 +114,16 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
                               const int32_t* tile_y, const int32_t* tile_x, int mirror_mask, const uint16_t* gaussian_f16,
                               uint16_t* logits_f16, uint8_t* seg_u8);
 
+/* Coronal maximum + mean projection of a volume on the device (reference ts2d/tool.py:152-160 -> ts2d/core/util/image.py:46-101).
+ *   volume     host pointer to the ORIGINAL contiguous buffer of `n_elems` elements of type `dtype`
+ *              (0 = int16, 1 = uint8, 2 = float32, 3 = uint16, 4 = int32)
+ *   nz, ny, nx extents of the REORIENTED view [z][y][x] (DICOMOrient 'RAI'); sz, sy, sx its signed ELEMENT strides and `base` the
+ *              element offset of view[0][0][0] in the buffer (so axis flips / permutations need no host copy)
+ *   out_max, out_mean  host [nz][nx] float32: projections along y.  Integer volumes: the mean is the exact sum divided with
+ *              truncation back to the integer type (ITK behaviour), then converted to float.  Synchronous. */
+int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
+                         long long sy, long long sx, long long base, float* out_max, float* out_mean);
+
 /* Pre-allocate the activation workspace for (B, H, W) (reference warm-up contract: a zero patch is pushed through
  * the predictor once at start-up, prediction_worker.py:74-96,136-138). */
 int ts2d_engine_reserve(ts2d_engine* e, int B, int H, int W);

@@ -31,3 +31,26 @@ def test_predict_matches_oracle_pipeline(asset, collapse, tmp_path):
         files = a.save(dest=str(tmp_path), name='case', models='all', targets=['segmentation', 'projection'], content='file')
         assert os.path.exists(os.path.join(str(tmp_path), 'case.seg.nrrd')) and len(files) >= 3
         assert nrrd.read(os.path.join(str(tmp_path), 'case.seg.nrrd')).components == 7
+
+
+def test_gpu_projection_equals_host_projection():
+    """ts2d_project_coronal (strided view, no reorientation copy) == reorient_image + project on the host, bit for bit."""
+    from totalsegmentator2d_amd import image
+    v = nrrd.read(os.path.join(A, 'sample_s0521.nrrd'))                                   # int16, direction diag(-1,-1,1)
+    rng = np.random.default_rng(3)
+    vols = [v,
+            nrrd.Image(rng.normal(0, 300, (40, 33, 50)).astype(np.float32), (1.0, 2.0, 3.0), (5.0, -7.0, 11.0),
+                       (0.0, -1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, -1.0), 1, {}, 'left-posterior-superior'),   # permuted + flipped axes
+            nrrd.Image(rng.integers(0, 255, (20, 16, 24)).astype(np.uint8), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0),
+                       (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0), 1, {}, None)]
+    for vol in vols:
+        got = image.project_coronal_gpu(vol)
+        r = image.reorient_image(vol)
+        for mode in ('max', 'mean'):
+            ref = image.cast(image.project(r, mode, 'coronal'), np.float32)
+            assert got[mode].size == ref.size and got[mode].spacing == ref.spacing
+            assert np.allclose(got[mode].origin, ref.origin) and np.allclose(got[mode].direction, ref.direction)
+            if vol.array.dtype == np.float32 and mode == 'mean':
+                assert np.allclose(got[mode].array, ref.array, rtol=1e-6, atol=1e-4)
+            else:
+                assert np.array_equal(got[mode].array, ref.array), mode

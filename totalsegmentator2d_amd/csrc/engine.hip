@@ -9,6 +9,7 @@
 #include "kernels_f16x3_pp.h"
 #include "kernels_first.h"
 #include "kernels_sw.h"
+#include "kernels_project.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -887,6 +888,42 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
     if (logits_f16) HIP_TRY(hipMemcpyAsync(logits_f16, d_o16, (size_t)K * Hp * Wp * 2, hipMemcpyDeviceToHost, st));
     if (seg_u8) HIP_TRY(hipMemcpyAsync(seg_u8, d_seg, (size_t)K * Hp * Wp, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return TS2D_OK;
+}
+
+int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
+                         long long sy, long long sx, long long base, float* out_max, float* out_mean) {
+    if (!volume || !out_max || !out_mean) return fail(TS2D_ERR_INVALID, "ts2d_project_coronal: null argument");
+    static const int esize[5] = {2, 1, 4, 2, 4};
+    if (dtype < 0 || dtype > 4 || nz < 1 || ny < 1 || nx < 1) return fail(TS2D_ERR_INVALID, "ts2d_project_coronal: bad dtype / extents");
+    {   // every element the view can touch must lie inside the buffer
+        long long lo = base, hi = base;
+        const long long ext[3] = {(long long)(nz - 1) * sz, (long long)(ny - 1) * sy, (long long)(nx - 1) * sx};
+        for (int k = 0; k < 3; ++k) { if (ext[k] < 0) lo += ext[k]; else hi += ext[k]; }
+        if (lo < 0 || hi >= (long long)n_elems) return fail(TS2D_ERR_INVALID, "ts2d_project_coronal: the strided view leaves the buffer");
+    }
+    HIP_TRY(hipSetDevice(device));
+    const size_t vbytes = n_elems * esize[dtype], obytes = (size_t)nz * nx * sizeof(float);
+    char* d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), align_up(vbytes, 256) + 2 * align_up(obytes, 256)));
+    float* d_max = reinterpret_cast<float*>(d + align_up(vbytes, 256));
+    float* d_mean = reinterpret_cast<float*>(d + align_up(vbytes, 256) + align_up(obytes, 256));
+    hipError_t he = hipMemcpy(d, volume, vbytes, hipMemcpyHostToDevice);
+    if (he == hipSuccess) {
+        const unsigned grid = (unsigned)(((long long)nz * nx + 255) / 256);
+        switch (dtype) {
+            case 0: hipLaunchKernelGGL(project_coronal<int16_t>, dim3(grid), dim3(256), 0, 0, reinterpret_cast<const int16_t*>(d), nz, ny, nx, sz, sy, sx, base, d_max, d_mean); break;
+            case 1: hipLaunchKernelGGL(project_coronal<uint8_t>, dim3(grid), dim3(256), 0, 0, reinterpret_cast<const uint8_t*>(d), nz, ny, nx, sz, sy, sx, base, d_max, d_mean); break;
+            case 2: hipLaunchKernelGGL(project_coronal<float>, dim3(grid), dim3(256), 0, 0, reinterpret_cast<const float*>(d), nz, ny, nx, sz, sy, sx, base, d_max, d_mean); break;
+            case 3: hipLaunchKernelGGL(project_coronal<uint16_t>, dim3(grid), dim3(256), 0, 0, reinterpret_cast<const uint16_t*>(d), nz, ny, nx, sz, sy, sx, base, d_max, d_mean); break;
+            default: hipLaunchKernelGGL(project_coronal<int32_t>, dim3(grid), dim3(256), 0, 0, reinterpret_cast<const int32_t*>(d), nz, ny, nx, sz, sy, sx, base, d_max, d_mean); break;
+        }
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpy(out_max, d_max, obytes, hipMemcpyDeviceToHost);
+    if (he == hipSuccess) he = hipMemcpy(out_mean, d_mean, obytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (he != hipSuccess) return fail(TS2D_ERR_HIP, "ts2d_project_coronal failed: %s", hipGetErrorString(he));
     return TS2D_OK;
 }
 

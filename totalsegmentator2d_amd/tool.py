@@ -55,6 +55,8 @@ class TS2D:
                 raise RuntimeError(f"Failed to load model {mid}") from ex
         for model in self.models.values():
             model.await_startup()
+        # GPU projection only on the product path (models backed by HIP engines, not by the CPU test hook)
+        self._gpu_projection = all(m._config.get('network') is None for m in self.models.values())
 
     def __enter__(self):
         return self
@@ -91,7 +93,16 @@ class TS2D:
         channels = sorted(model.channels.items())
         projections = cache.setdefault('projections', {})
         if get_actual_dimension(input) > 2:
-            input = reorient_image(input, 'RAI')
+            need = [n for _, n in channels if n not in projections]
+            if need and self._gpu_projection and input.components == 1 and input.array.dtype.name in ('int16', 'uint8', 'float32', 'uint16', 'int32') \
+                    and all(n.lower() in ('max', 'mip', 'mean', 'avg') for n in need):
+                # product path: both projections in one pass over the volume on the GPU, reorientation folded into the strides
+                from .image import project_coronal_gpu
+                pr = project_coronal_gpu(input, getattr(model._predictor.device, 'index', 0) or 0)
+                for n in need:
+                    projections[n] = pr['max' if n.lower() in ('max', 'mip') else 'mean']
+            else:
+                input = reorient_image(input, 'RAI')
             chs = []
             for _, ch_name in channels:                      # channel NAME = projection mode (reference tool.py:156-158)
                 if ch_name not in projections:
