@@ -16,8 +16,10 @@ A = os.path.join(GOLDEN, 'assets')
 @pytest.mark.parametrize('asset,collapse', [('sample_s0521.nrrd', False), ('sample_s0616.nrrd', False), ('sample_s0332.nrrd', True)])
 def test_predict_matches_oracle_pipeline(asset, collapse, tmp_path):
     ids = ('ts2d-v2-ep4000b2_cardiac', 'ts2d-v2-ep4000b2_ribs')
-    gpu = {m: synthetic_model(m, 3 + i, 31 + i)[0] for i, m in enumerate(ids)}                       # HIP engines, mirroring on
-    ref = {m: synthetic_model(m, 3 + i, 31 + i, network=True)[0] for i, m in enumerate(ids)}        # torch oracle underneath
+    mirror = asset == 'sample_s0521.nrrd'                    # mirroring TTA on the small volume only (keeps the oracle side short)
+    patch = (64, 64) if mirror else (128, 128)
+    gpu = {m: synthetic_model(m, 3 + i, 31 + i, patch=patch, mirror=mirror)[0] for i, m in enumerate(ids)}                # HIP engines
+    ref = {m: synthetic_model(m, 3 + i, 31 + i, patch=patch, mirror=mirror, network=True)[0] for i, m in enumerate(ids)}  # torch oracle
     with TS2D(models=gpu) as ts, TS2D(models=ref) as tr:
         a = ts.predict(os.path.join(A, asset), collapse=collapse)
         b = tr.predict(os.path.join(A, asset), collapse=collapse)
