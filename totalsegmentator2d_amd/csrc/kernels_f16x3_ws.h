@@ -61,6 +61,13 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv3x3_f16x3_ws(const ConvArgs
         int goff[3];
         f32x4 pv[3][2];
         int wst0 = -1, wst1 = -1;         // column tile whose weights currently sit in each stage (residency for <= 2 chunks)
+        // weights of the HELD step, prefetched one full phase ahead like the patch (named registers: arrays captured by the
+        // lambdas below were demoted to scratch by the compiler)
+        constexpr int WU = 9 * BN * 4, WIT = (WU + 255) / 256;
+        uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8;
+        bool w_need = false;
+#define TS2D_WS_WLOAD(K, R) { const int idx = ptid + K * 256; if (K < WIT && idx < WU) R = wsrc_[idx]; }
+#define TS2D_WS_WSTORE(K, R) { const int idx = ptid + K * 256; if (K < WIT && idx < WU) *reinterpret_cast<uint4*>(sB_ + (idx >> 2) * kRec + (idx & 3) * 16) = R; }
 
         auto plan = [&](int vb) {
             int n, ty0, tx0, tin, n0col;
@@ -93,10 +100,9 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv3x3_f16x3_ws(const ConvArgs
             }
         };
         // write the step held in registers (item image n_w, chunk ch_w, validity vmask) into `stage`
-        auto write_step = [&](unsigned char* stage, int n_w, int ch_w, int vmask, int n0col_w, bool stage_w) {
+        auto write_step = [&](unsigned char* stage, int n_w, int ch_w, int vmask, bool stage_w) {
             unsigned char* sA = stage;
-            unsigned char* sB = stage + P * kRec;
-            constexpr int WU = 9 * BN * 4;
+            unsigned char* sB_ = stage + P * kRec;
             int cb = ch_w * 16;
             const float* sc = a.sc0; const float* sh = a.sh0; int C = a.C0;
             if (cb >= a.C0) { cb -= a.C0; sc = a.sc1; sh = a.sh1; C = a.C1; }
@@ -131,15 +137,9 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv3x3_f16x3_ws(const ConvArgs
                     *reinterpret_cast<half8*>(d + 32) = lo;
                 }
             }
-            if (stage_w) {                  // weights of this chunk (L2-resident): global -> LDS records
-                const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch_w * a.n_ctiles + n0col_w / BN) * (9 * BN * 4);
-#pragma unroll
-                for (int it = 0; it < (WU + 255) / 256; ++it) {
-                    const int idx = ptid + it * 256;
-                    if (idx < WU) {
-                        *reinterpret_cast<uint4*>(sB + (idx >> 2) * kRec + (idx & 3) * 16) = wsrc[idx];
-                    }
-                }
+            if (stage_w) {                  // weight registers (loaded a phase ago) -> LDS records
+                TS2D_WS_WSTORE(0, w0) TS2D_WS_WSTORE(1, w1) TS2D_WS_WSTORE(2, w2) TS2D_WS_WSTORE(3, w3) TS2D_WS_WSTORE(4, w4)
+                TS2D_WS_WSTORE(5, w5) TS2D_WS_WSTORE(6, w6) TS2D_WS_WSTORE(7, w7) TS2D_WS_WSTORE(8, w8)
             }
         };
         auto flush_red = [&](int vb) {      // 4 consumer waves' partial (sum, sum of squares) -> global partial buffer
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv3x3_f16x3_ws(const ConvArgs
         };
 
         // cursors: (l_vb, l_ch) next step to LOAD; registers currently hold step (w_vb, w_ch)
-        int l_vb = next_valid(blockIdx.x), l_ch = 0;
+        int l_vb = next_valid(blockIdx.x), l_ch = 0, l_p = 0;          // l_p = step index of the load cursor (stage = l_p & 1)
         int w_vb = -1, w_ch = 0, w_mask = 0;
         auto advance_load = [&]() {          // registers <- step (l_vb, l_ch); move the load cursor on
             w_vb = l_vb; w_ch = l_ch;
@@ -163,6 +163,17 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv3x3_f16x3_ws(const ConvArgs
                 if (l_ch == 0) plan(l_vb);
                 w_mask = (goff[0] >= 0 ? 1 : 0) | (goff[1] >= 0 ? 2 : 0) | (goff[2] >= 0 ? 4 : 0);
                 issue_loads(l_ch);
+                {   // weights of that step, unless the stage it will go to still holds them (<= 2 chunks, same column tile)
+                    int mt_, ct_;
+                    decode(l_vb, mt_, ct_);
+                    w_need = !(nchunks <= 2 && ((l_p & 1) ? wst1 : wst0) == ct_);
+                    if (w_need) {
+                        const uint4* wsrc_ = reinterpret_cast<const uint4*>(a.wph) + ((size_t)l_ch * a.n_ctiles + ct_) * (9 * BN * 4);
+                        TS2D_WS_WLOAD(0, w0) TS2D_WS_WLOAD(1, w1) TS2D_WS_WLOAD(2, w2) TS2D_WS_WLOAD(3, w3) TS2D_WS_WLOAD(4, w4)
+                        TS2D_WS_WLOAD(5, w5) TS2D_WS_WLOAD(6, w6) TS2D_WS_WLOAD(7, w7) TS2D_WS_WLOAD(8, w8)
+                    }
+                }
+                ++l_p;
                 if (++l_ch == nchunks) { l_ch = 0; l_vb = next_valid(l_vb + G); }
             }
         };
@@ -170,8 +181,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv3x3_f16x3_ws(const ConvArgs
             int n, ty0, tx0, tin, n0col;
             item_coords(w_vb, n, ty0, tx0, tin, n0col);
             const int ct = n0col / BN;
-            const bool stage_w = !(nchunks <= 2 && ((p & 1) ? wst1 : wst0) == ct);
-            write_step(stage0 + (p & 1) * stage_bytes, n, w_ch, w_mask, n0col, stage_w);
+            write_step(stage0 + (p & 1) * stage_bytes, n, w_ch, w_mask, w_need);
             if (p & 1) wst1 = (nchunks <= 2) ? ct : -1; else wst0 = (nchunks <= 2) ? ct : -1;
         };
 
@@ -189,6 +199,8 @@ __global__ __launch_bounds__(kWsThreads, 2) void conv3x3_f16x3_ws(const ConvArgs
             c_vb = next_valid(c_vb + G);
         }
         if (prev_end_vb >= 0) flush_red(prev_end_vb);
+#undef TS2D_WS_WLOAD
+#undef TS2D_WS_WSTORE
     } else {
         // =============================================================== CONSUMER
         __builtin_amdgcn_s_setprio(1);
