@@ -7,6 +7,8 @@
 #include "kernels_f16x3_ws.h"
 #include "kernels_f16x3_convt.h"
 #include "kernels_f16x3_pp.h"
+#include "kernels_h32.h"
+#include "kernels_f16x3_one.h"
 #include "kernels_first.h"
 #include "kernels_sw.h"
 #include "kernels_project.h"
@@ -59,6 +61,8 @@ struct Op {
     size_t dev_w_floats;
     bool split_ok = false;        // eligible for the split-fp16 kernel (3x3, stride 1, Cin % 16 == 0, not the net input)
     size_t dev_wh = 0;            // offset (floats) of the split-fp16 weights in the arena
+    size_t dev_wh32 = 0;          // offset (floats) of the fp16 weights in 32-channel chunks (precision mode f16, kernels_h32.h)
+    bool h32_ok = false;
     size_t dev_ws = 0;            // offset (floats) of 1 / (power-of-two pre-scale of the split weights)
     bool first_direct = false;    // first conv block handled by conv3x3_first (reads the NCHW boundary tensor)
     size_t dev_wraw = 0;
@@ -85,6 +89,8 @@ struct ts2d_engine {
     bool use_ws = false;          // warp-specialised persistent split kernel: opt-in experiment (TS2D_WS=1); measured
                                   // slower than two independent 256-thread workgroups per CU in round 1
     int num_cus = 256;
+    bool use_h32 = true;          // precision mode f16: 32-channel-chunk kernel (TS2D_H32=0 falls back to the 16-channel one)
+    bool use_one = true;          // one-image-tile split kernel (TS2D_ONE=0 falls back to the generic one)
     bool use_pp = false;          // ping-pong split kernel: opt-in experiment (TS2D_PP=1); measured slower in round 1
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
@@ -191,6 +197,10 @@ int build_program(ts2d_engine* e) {
             const size_t recs = op.stride == 1 ? (size_t)(ct / 16) * 9 : (size_t)(ct / 8) * 5;
             op.dev_wh = wo; wo = align_up(wo + recs * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);                  // 1 / scale, read by the kernel
+            if (op.stride == 1 && op.cin % 32 == 0 && op.cin_skip % 32 == 0) {      // [chunk32][column tile][tap][column][32 halves]
+                op.h32_ok = true;
+                op.dev_wh32 = wo; wo = align_up(wo + (size_t)(ct / 32) * 9 * op.cout * 16, 64);
+            }
         }
         if (op.type == OP_CONV && op.src == 0 && ct <= 4) {              // first block: PyTorch-layout fp32 copy for conv3x3_first
             op.dev_wraw = wo; wo = align_up(wo + (size_t)op.cout * ct * 9, 64);
@@ -281,6 +291,8 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                             const int chunk = ci / 16, cc = ci % 16, bn = co_n % 64 == 0 ? 64 : 32;
                             uint16_t* rec = d + ((((size_t)chunk * (co_n / bn) + co / bn) * 9 + tap) * bn + co % bn) * 32;
                             rec[cc] = hi; rec[16 + cc] = lo;
+                            if (op.h32_ok)          // same blocks with 32 real channels per record (the hi parts only)
+                                reinterpret_cast<uint16_t*>(out + op.dev_wh32)[((((size_t)(ci / 32) * (co_n / bn) + co / bn) * 9 + tap) * bn + co % bn) * 32 + ci % 32] = hi;
                         } else {       // K packed as 8 channels x 2 taps: k = 8 * (tap & 1) + (ci % 8) of k-step tap / 2
                             const int chunk = ci / 8, cc = (tap & 1) * 8 + ci % 8;
                             uint16_t* rec = d + (((size_t)chunk * 5 + tap / 2) * co_n + co) * 32;
@@ -399,6 +411,42 @@ hipError_t launch_split_t(int bn, int maxu, const ConvArgs& a, int grid, size_t 
 }
 hipError_t launch_split(bool f16, int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
     return f16 ? launch_split_t<_Float16, 1>(bn, maxu, a, grid, smem, st) : launch_split_t<float, 3>(bn, maxu, a, grid, smem, st);
+}
+
+template <int BN, bool PFS>
+hipError_t launch_one_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv3x3_f16x3_one<BN, PFS>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_one(int bn, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    if (bn == 32) return launch_one_inst<32, false>(a, grid, smem, st);     // 3 workgroups per CU: no room for the prefetched scale/shift
+    if (bn == 64) return launch_one_inst<64, true>(a, grid, smem, st);
+    return hipErrorInvalidConfiguration;
+}
+
+template <int BN, int MAXU>
+hipError_t launch_h32_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv3x3_h32<BN, MAXU>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_h32(int bn, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    if (bn == 32) return launch_h32_inst<32, 6>(a, grid, smem, st);
+    if (bn == 64) return launch_h32_inst<64, 6>(a, grid, smem, st);
+    return hipErrorInvalidConfiguration;
 }
 
 template <int BN, int MAXU, typename ST, int NP>
@@ -667,7 +715,16 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             hipError_t le;
             const size_t smem_pp = 2 * ((size_t)P * kRec + (size_t)9 * bn * kRec) + (size_t)2 * 4 * bn * 2 * sizeof(float);
             const bool pp = split && !f16 && stride == 1 && !ws && e->use_pp && smem_pp <= 160 * 1024;
-            if (pp) {      // ping-pong kernel: two pixel tiles per 512-thread workgroup in enforced anti-phase
+            // (both one-image kernels address a source image through a 32-bit buffer offset)
+            const bool img32 = (size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4 < ((size_t)1 << 31);
+            const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
+            const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32 && !e->use_ws && !e->use_pp;
+            if (one) {     // tile inside one image: lean staging path
+                le = launch_one(bn, ca, grid, smem, st);
+            } else if (h32) {     // fp16 storage: 32-channel chunks, one product
+                ca.wph = wts + op.dev_wh32;
+                le = launch_h32(bn, ca, grid, smem, st);
+            } else if (pp) {      // ping-pong kernel: two pixel tiles per 512-thread workgroup in enforced anti-phase
                 const int n_pairs = (g.n_mtiles + 1) / 2;
                 le = launch_split_pp(bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, (n_pairs + 7) / 8 * 8 * ca.n_ctiles, smem_pp, st);
             } else if (ws) {
@@ -748,6 +805,8 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
         if (getenv("TS2D_PP")) e->use_pp = getenv("TS2D_PP")[0] == '1';
+        if (getenv("TS2D_H32")) e->use_h32 = getenv("TS2D_H32")[0] == '1';
+        if (getenv("TS2D_ONE")) e->use_one = getenv("TS2D_ONE")[0] == '1';
         const char* ws = getenv("TS2D_WS");
         e->use_ws = ws && ws[0] == '1';
     }

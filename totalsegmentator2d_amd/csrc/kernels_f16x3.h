@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
         // the weight image holds one contiguous [tap][column][16 hi | 16 lo] block per (chunk, column tile): no index arithmetic
         const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * a.n_ctiles + ctile) * (9 * BN * 4);
         uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8;
-#define TS2D_WLOAD(K, R) { const int idx = tid + K * kBlock; if (K < WIT && idx < WU && (NP == 3 || (idx & 2) == 0)) R = wsrc[idx]; }
+#define TS2D_WLOAD(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU) && (NP == 3 || (idx & 2) == 0)) R = wsrc[idx]; }
         TS2D_WLOAD(0, w0) TS2D_WLOAD(1, w1) TS2D_WLOAD(2, w2) TS2D_WLOAD(3, w3) TS2D_WLOAD(4, w4)
         TS2D_WLOAD(5, w5) TS2D_WLOAD(6, w6) TS2D_WLOAD(7, w7) TS2D_WLOAD(8, w8)
 #undef TS2D_WLOAD
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
             }
         }
         // ---- weight registers -> LDS records [tap][col][hi16 | lo16 | pad]
-#define TS2D_WSTORE(K, R) { const int idx = tid + K * kBlock; if (K < WIT && idx < WU && (NP == 3 || (idx & 2) == 0)) \
+#define TS2D_WSTORE(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU) && (NP == 3 || (idx & 2) == 0)) \
             *reinterpret_cast<uint4*>(sB + (idx >> 2) * kRec + (idx & 3) * 16) = R; }
         TS2D_WSTORE(0, w0) TS2D_WSTORE(1, w1) TS2D_WSTORE(2, w2) TS2D_WSTORE(3, w3) TS2D_WSTORE(4, w4)
         TS2D_WSTORE(5, w5) TS2D_WSTORE(6, w6) TS2D_WSTORE(7, w7) TS2D_WSTORE(8, w8)
