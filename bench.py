@@ -177,7 +177,8 @@ def main():
                         'f16': 'f16 storage + f16 MFMA, f32 accumulate/statistics (NOT within the fp32 parity tolerance)'}[args.precision]
         out['precision_mode'] = args.precision
         if profile and op_ms:
-            # dominant kernel = the stride-1 3x3 implicit-GEMM conv (conv3x3_f16x3 / conv_mfma_f32<9,1,..>): 22 launches/step
+            # dominant kernel = the stride-1 3x3 implicit-GEMM conv (conv3x3_f16x3_one + conv3x3_f16x3 on the 8x8/4x4 levels /
+            # conv3x3_h32 / conv_mfma_f32<9,1,..>): 22 launches/step
             prog = arch.program()
             per = {o['name']: 2.0 * m['macs'] for o, m in zip(prog, work['per_layer'])
                    if o['op'] == OP_CONV3X3 and o['stride'] == 1 and o['src'] != 'input'}
@@ -195,7 +196,8 @@ def main():
             all3 = {o['name'] for o in prog if o['op'] == OP_CONV3X3}
             out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                                'frac': round(achieved / peak, 4), 'traffic': traffic,
-                               'kernel': ('conv3x3_f16x3' if split else 'conv_mfma_f32<9,1,16,*>') + f' ({len(per)} launches/step)',
+                               'kernel': {'split': 'conv3x3_f16x3_one (18) + conv3x3_f16x3 (4)', 'f16': 'conv3x3_h32 (18) + conv3x3_f16x3<f16> (4)',
+                                          'exact': 'conv_mfma_f32<9,1,16,*>'}[args.precision] + f' ({len(per)} launches/step)',
                                'peak_note': ('dense fp16 MFMA 2500 TFLOP/s / 3 products per MAC' if split else 'fp32 MFMA 32x32x2'),
                                'algorithmic_flop_per_launch_avg': round(conv_flops / len(per)),
                                'kernel_ms_per_launch_avg': round(conv_ms / len(per), 4),

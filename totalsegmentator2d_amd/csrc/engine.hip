@@ -193,7 +193,7 @@ int build_program(ts2d_engine* e) {
         op.dev_b = wo; wo = align_up(wo + op.cout, 64);
         if (op.type == OP_CONV) { op.dev_g = wo; wo = align_up(wo + op.cout, 64); op.dev_be = wo; wo = align_up(wo + op.cout, 64); }
         if (op.type == OP_CONV && op.src != 0 && ((op.stride == 1 && ct % 16 == 0) || (op.stride == 2 && ct % 8 == 0))) {
-            op.split_ok = true;        // stride 1: [chunk16][tap 9][Cout][32 halves]; stride 2: [chunk8][k-step 5][Cout][32 halves]
+            op.split_ok = true;        // stride 1: [chunk16][tap 9][Cout][32 halves]; stride 2: [chunk8][column tile][k-step 5][column][32 halves]
             const size_t recs = op.stride == 1 ? (size_t)(ct / 16) * 9 : (size_t)(ct / 8) * 5;
             op.dev_wh = wo; wo = align_up(wo + recs * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);                  // 1 / scale, read by the kernel
@@ -294,8 +294,8 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                             if (op.h32_ok)          // same blocks with 32 real channels per record (the hi parts only)
                                 reinterpret_cast<uint16_t*>(out + op.dev_wh32)[((((size_t)(ci / 32) * (co_n / bn) + co / bn) * 9 + tap) * bn + co % bn) * 32 + ci % 32] = hi;
                         } else {       // K packed as 8 channels x 2 taps: k = 8 * (tap & 1) + (ci % 8) of k-step tap / 2
-                            const int chunk = ci / 8, cc = (tap & 1) * 8 + ci % 8;
-                            uint16_t* rec = d + (((size_t)chunk * 5 + tap / 2) * co_n + co) * 32;
+                            const int chunk = ci / 8, cc = (tap & 1) * 8 + ci % 8, bn = co_n % 64 == 0 ? 64 : 32;
+                            uint16_t* rec = d + ((((size_t)chunk * (co_n / bn) + co / bn) * 5 + tap / 2) * bn + co % bn) * 32;
                             rec[cc] = hi; rec[16 + cc] = lo;
                         }
                     }
@@ -424,6 +424,24 @@ hipError_t launch_one_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t
     }
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
+}
+template <int BN, bool PFS, bool PIPE>
+hipError_t launch_one_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv3x3s2_f16x3_one<BN, PFS, PIPE>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_one_s2(int bn, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    if (bn == 32) return launch_one_s2_inst<32, false, false>(a, grid, smem, st);
+    // (measured: prefetching the scale/shift vectors or double-buffering the fragments costs registers and gains nothing here)
+    if (bn == 64) return launch_one_s2_inst<64, false, false>(a, grid, smem, st);
+    return hipErrorInvalidConfiguration;
 }
 hipError_t launch_one(int bn, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
     if (bn == 32) return launch_one_inst<32, false>(a, grid, smem, st);     // 3 workgroups per CU: no room for the prefetched scale/shift
@@ -719,8 +737,11 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             const bool img32 = (size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4 < ((size_t)1 << 31);
             const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
             const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32 && !e->use_ws && !e->use_pp;
+            const bool one_s2 = split && !f16 && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;
             if (one) {     // tile inside one image: lean staging path
                 le = launch_one(bn, ca, grid, smem, st);
+            } else if (one_s2) {
+                le = launch_one_s2(bn, ca, grid, smem, st);
             } else if (h32) {     // fp16 storage: 32-channel chunks, one product
                 ca.wph = wts + op.dev_wh32;
                 le = launch_h32(bn, ca, grid, smem, st);

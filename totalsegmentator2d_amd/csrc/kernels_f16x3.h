@@ -485,15 +485,13 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
         }
         {
             constexpr int WU = 5 * BN * 4;
-            const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * 5 * a.N + n0col) * 4;
+            // one contiguous [k-step][column][16 hi | 16 lo] block per (chunk, column tile)
+            const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * a.n_ctiles + ctile) * (5 * BN * 4);
 #pragma unroll
             for (int it = 0; it < (WU + kBlock - 1) / kBlock; ++it) {
                 const int idx = tid + it * kBlock;
-                if (idx < WU && (NP == 3 || (idx & 2) == 0)) {
-                    const int tc = idx >> 2, part = idx & 3;
-                    const int ks = tc / BN, col = tc - ks * BN;
-                    *reinterpret_cast<uint4*>(sB + tc * kRec + part * 16) = wsrc[((size_t)ks * a.N + col) * 4 + part];
-                }
+                if ((WU % kBlock == 0 || idx < WU) && (NP == 3 || (idx & 2) == 0))
+                    *reinterpret_cast<uint4*>(sB + (idx >> 2) * kRec + (idx & 3) * 16) = wsrc[idx];
             }
         }
         __syncthreads();

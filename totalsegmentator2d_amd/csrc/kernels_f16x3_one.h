@@ -254,4 +254,232 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3_one(const ConvArgs a)
     split_epilogue<BN, float>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Stride-2 counterpart (the strided-conv downsample): arithmetic and LDS layout of conv3x3s2_f16x3, staging as above.
+// ------------------------------------------------------------------------------------------------------------
+template <int BN, bool PFS, bool PIPE>
+__global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs a) {
+    constexpr int NT = BN / 32, MAXU = 5;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = bid >> 3;
+    const int mtile = (q8 / a.n_ctiles) * 8 + xcd;
+    const int ctile = q8 % a.n_ctiles;
+    if (mtile >= a.n_mtiles) return;
+    const int n0col = ctile * BN;
+
+    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int nimg0 = mtile / tpi, tin = mtile - nimg0 * tpi;
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
+    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int P = a.PH * a.PW, PWe = (a.PW + 1) >> 1;
+    unsigned char* sA = smem8;                 // [P patch pixels, even columns first][48 B]
+    unsigned char* sB = smem8 + P * kRec8;     // [k-step 5][BN columns][80 B]
+
+    // ---- staging plan: unit u = one patch pixel (8 channels per chunk).  Buffer loads relative to the image base: a padding
+    //      pixel gets an out-of-range offset and is never staged - its LDS record is zeroed once, here.
+    unsigned poff[MAXU];                       // pixel index inside the image, or ~0u (padding / no unit)
+    int lrec[MAXU];
+    const float inv_pw = 1.0f / (float)a.PW;
+#pragma unroll
+    for (int it = 0; it < MAXU; ++it) {
+        const int u = tid + it * kBlock;
+        unsigned g = ~0u; int lr = 0;
+        if (u < P) {
+            const int py = (int)(((float)u + 0.5f) * inv_pw), px = u - py * a.PW;
+            const int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
+            lr = (py * a.PW + ((px & 1) ? PWe + (px >> 1) : (px >> 1))) * kRec8;
+            if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) g = (unsigned)(iy * a.Win + ix);
+            else { *reinterpret_cast<uint4*>(sA + lr) = uint4{0u, 0u, 0u, 0u}; *reinterpret_cast<uint4*>(sA + lr + 16) = uint4{0u, 0u, 0u, 0u}; }
+        }
+        poff[it] = g; lrec[it] = lr;
+    }
+
+    int abase[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = 64 * w + 32 * mt + r;
+        const int ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+        abase[mt] = (2 * ty * a.PW + tx) * kRec8;
+    }
+    int tofl[5];      // this lane half's tap offset per k-step (tap 9 does not exist: reuse tap 8, its weights are 0)
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int t = (2 * s + h) < 9 ? (2 * s + h) : 8;
+        const int dy = t / 3, dx = t - 3 * dy;
+        tofl[s] = (dy * a.PW + ((dx & 1) ? PWe : 0) + (dx >> 1)) * kRec8;
+    }
+    const int bbase = r * kRec + 16 * h;
+
+    f32x16 acc_t[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
+
+    const int nchunks = a.C0 / 8;              // the strided conv never reads a concat
+    const size_t img_px = (size_t)a.Hin * a.Win;
+    // one buffer descriptor per source tensor, based at this tile's image (wave-uniform)
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0) + (size_t)nimg0 * img_px * a.C0, 0, (int)(img_px * a.C0 * 4), 0x00020000);
+    unsigned vo0[MAXU];                        // per-unit byte offsets (chunk offset goes into the scalar offset)
+#pragma unroll
+    for (int it = 0; it < MAXU; ++it) vo0[it] = poff[it] == ~0u ? 0x80000000u : poff[it] * (unsigned)a.C0 * 4u;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 pv[MAXU][2];                         // raw fp32 patch values of the next chunk (in flight during the MFMAs)
+    f32x4 nsa = f32x4{1.f, 1.f, 1.f, 1.f}, nsb = nsa, nta = f32x4{0.f, 0.f, 0.f, 0.f}, ntb = nta;   // ... and its scale / shift
+
+    const int kper = (nchunks + a.ksplit - 1) / a.ksplit;
+    const int kbeg = (int)blockIdx.y * kper, kend = (kbeg + kper < nchunks) ? kbeg + kper : nchunks;
+    auto load_st = [&](int ch) {              // scale / shift of the chunk's 8 channels
+        if (a.sc0 != nullptr) {
+            const float* ps = a.sc0 + (size_t)nimg0 * a.C0 + ch * 8; const float* pt = a.sh0 + (size_t)nimg0 * a.C0 + ch * 8;
+            nsa = *reinterpret_cast<const f32x4*>(ps); nsb = *reinterpret_cast<const f32x4*>(ps + 4);
+            nta = *reinterpret_cast<const f32x4*>(pt); ntb = *reinterpret_cast<const f32x4*>(pt + 4);
+        }
+    };
+    auto prefetch = [&](int ch) {
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) {
+            pv[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rs0, vo0[it], ch * 32, 0);
+            pv[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rs0, vo0[it] + 16, ch * 32, 0);
+        }
+        if (PFS) load_st(ch);
+    };
+
+    if (kbeg < kend) prefetch(kbeg);
+    for (int ch = kbeg; ch < kend; ++ch) {
+        const bool normed = a.sc0 != nullptr;
+        __syncthreads();   // the previous chunk's MFMA reads of LDS are done
+        if (!PFS) load_st(ch);      // (register budget of the 3-workgroups-per-CU variant: loaded here, ahead of the weights)
+        // ---- weights of this chunk: loads issued first (named registers), latency hidden behind the patch conversion
+        constexpr int WU = 5 * BN * 4, WIT = (WU + kBlock - 1) / kBlock;
+        const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * a.n_ctiles + ctile) * (5 * BN * 4);
+        uint4 w0, w1, w2, w3, w4;
+#define TS2D_WLOAD(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU)) R = wsrc[idx]; }
+        TS2D_WLOAD(0, w0) TS2D_WLOAD(1, w1) TS2D_WLOAD(2, w2) TS2D_WLOAD(3, w3) TS2D_WLOAD(4, w4)
+#undef TS2D_WLOAD
+        // ---- patch: InstanceNorm + LeakyReLU on the fly, fp16 in -> fp16 LDS records (padding records stay zero)
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) {
+            if (poff[it] != ~0u) {
+                f32x4 va = __builtin_bit_cast(f32x4, pv[it][0]), vb = __builtin_bit_cast(f32x4, pv[it][1]);
+                if (normed) {
+                    va = va * nsa + nta; vb = vb * nsb + ntb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        va[e] = fmaxf(va[e], va[e] * a.slope);     // LeakyReLU (0 < slope < 1)
+                        vb[e] = fmaxf(vb[e], vb[e] * a.slope);
+                    }
+                }
+                half8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 ha = (_Float16)va[e], hb = (_Float16)vb[e];
+                    hi[e] = ha; hi[e + 4] = hb;
+                    lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb);
+                }
+                *reinterpret_cast<half8*>(sA + lrec[it]) = hi;
+                *reinterpret_cast<half8*>(sA + lrec[it] + 16) = lo;
+            }
+        }
+        // ---- weight registers -> LDS records [k-step][col][16 hi | 16 lo | pad]
+#define TS2D_WSTORE(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU)) \
+            *reinterpret_cast<uint4*>(sB + (idx >> 2) * kRec + (idx & 3) * 16) = R; }
+        TS2D_WSTORE(0, w0) TS2D_WSTORE(1, w1) TS2D_WSTORE(2, w2) TS2D_WSTORE(3, w3) TS2D_WSTORE(4, w4)
+#undef TS2D_WSTORE
+        __syncthreads();
+        if (ch + 1 < kend) prefetch(ch + 1);       // HBM latency hides behind the MFMA phase
+
+        f32x16 acc_c[2][NT];                        // fresh accumulator per 8-channel chunk (accuracy)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc_c[mt][nt][i] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PIPE) {
+        // software-pipelined over the 5 k-steps: fragments of step s+1 are read while the MFMAs of step s run
+        half8 fa[2][2][2], fb[2][NT][2];            // [buffer][tile][hi, lo]
+        auto load_frags = [&](int buf, int s) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                fa[buf][mt][0] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s]);
+                fa[buf][mt][1] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s] + 16);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                fb[buf][nt][0] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase);
+                fb[buf][nt][1] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase + 32);
+            }
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < 5) load_frags(cur ^ 1, s + 1);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][1], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][1], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        } else {
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            half8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s] + 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bh[nt] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) ah[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bl[nt] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase + 32);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+        }
+        }
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
+    }
+
+    split_epilogue<BN, float>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
+}
+
 }  // namespace ts2d
