@@ -102,6 +102,74 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
     }
 }
 
+// Epilogue of the one-image-tile kernels (lgNIMG == 0, ksplit == 1).  When the 256-pixel tile lies completely inside the output
+// image, the 16 rows a lane holds of a 32x32 block differ from the lane's first row by a WAVE-UNIFORM element offset
+// ((rowoff & (TW-1)) + (rowoff >> lgTW) * Wt pixels, rowoff = (i&3) + 8*(i>>2); the lane part 4*(lane>>5) never carries across
+// a tile row since TW >= 16): buffer stores with one per-lane base offset per 32x32 block and a scalar offset per row - no
+// per-element address arithmetic, bounds tests or exec-mask regions (the generic epilogue spends ~30 VALU + 14 SALU per row).
+// Same values, same statistics order as split_epilogue.
+template <typename ST> __device__ __forceinline__ void buffer_store_act(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ void buffer_store_act<float>(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void buffer_store_act<_Float16>(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), rs, voff, soff, 0);
+}
+
+template <int BN, typename ST = float>
+__device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&acc_t)[2][BN / 32], unsigned char* smem8,
+                                                   int n0col, int nimg0, int ty0, int tx0, int tpi, int tin) {
+    constexpr int NT = BN / 32;
+    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW;
+    const bool full = a.ksplit == 1 && ty0 + TH <= a.Ht && tx0 + TW <= a.Wt && a.lgTW >= 4 && nimg0 < a.B;     // wave-uniform
+    if (!full) { split_epilogue<BN, ST>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin); return; }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const float oscale = *a.oscale;
+    const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * sizeof(ST)), 0x00020000);
+    float st_s[NT], st_q[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = n0col + nt * 32 + r;
+        const float bv = a.bias[co];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m0 = 64 * w + 32 * mt + 4 * h;                 // the lane's first row of this block
+            const int oy = ty0 + (m0 >> a.lgTW), ox = tx0 + (m0 & (TW - 1));
+            const unsigned voff = (unsigned)(((oy * a.Wt + ox) * a.Cout + co) * (int)sizeof(ST));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rowoff = (i & 3) + 8 * (i >> 2);
+                const unsigned soff = (unsigned)((((rowoff & (TW - 1)) + (rowoff >> a.lgTW) * a.Wt) * a.Cout) * (int)sizeof(ST));   // scalar
+                float v = acc_t[mt][nt][i] * oscale + bv;
+                buffer_store_act<ST>(v, rs, voff, soff);
+                v = round_act<ST>(v);                                                // statistics of what is stored
+                s += v; q += v * v;
+            }
+        }
+        st_s[nt] = s; st_q[nt] = q;
+    }
+    if (a.part != nullptr) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem8);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s = st_s[nt], q = st_q[nt];
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
+            float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
+            p[0] = s; p[1] = q;
+        }
+    }
+}
+
 // PF = chunks of raw patch data kept in flight in registers (2 for the HBM-bound small-Cin layers: more bytes in flight).
 template <int BN, int MAXU, int PF = 1, typename ST = float, int NP = 3>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {

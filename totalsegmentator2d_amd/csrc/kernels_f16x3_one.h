@@ -9,6 +9,94 @@
 
 namespace ts2d {
 
+// One chunk of the stride-1 contraction: 9 taps x (lo*hi + hi*lo + hi*hi) into a fresh accumulator, added to acc_t.
+template <int BN>
+__device__ __forceinline__ void split_mfma_chunk_s1(const unsigned char* sA, const unsigned char* sB, const int (&abase)[2], int bbase,
+                                                    const ConvArgs& a, f32x16 (&acc_t)[2][BN / 32]) {
+    constexpr int NT = BN / 32;
+    f32x16 acc_c[2][NT];                        // fresh accumulator per 16-channel chunk (accuracy)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_c[mt][nt][i] = 0.f;
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (BN == 64) {
+    // software-pipelined over the 9 taps: fragments of tap t+1 are read while the MFMAs of tap t run
+    half8 fa[2][2][2], fb[2][NT][2];            // [buffer][tile][hi, lo]
+    auto load_frags = [&](int buf, int tap) {
+        const int toff = ((tap / 3) * a.PW + (tap % 3)) * kRec;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            fa[buf][mt][0] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff);
+            fa[buf][mt][1] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff + 32);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            fb[buf][nt][0] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase);
+            fb[buf][nt][1] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase + 32);
+        }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int cur = tap & 1;
+        if (tap + 1 < 9) load_frags(cur ^ 1, tap + 1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][1], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][1], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    } else {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int toff = ((tap / 3) * a.PW + (tap % 3)) * kRec;
+        half8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff + 32);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bh[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ah[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bl[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase + 32);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+    }
+    }
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
+}
+
 template <int BN, bool PFS>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3_one(const ConvArgs a) {
     constexpr int NT = BN / 32, MAXU = 3;
@@ -168,90 +256,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3_one(const ConvArgs a)
         __syncthreads();
         if (ch + 1 < kend) prefetch(ch + 1);       // HBM latency hides behind the MFMA phase
 
-        f32x16 acc_c[2][NT];                        // fresh accumulator per 16-channel chunk (accuracy)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc_c[mt][nt][i] = 0.f;
-        __builtin_amdgcn_s_setprio(1);
-        if constexpr (BN == 64) {
-        // software-pipelined over the 9 taps: fragments of tap t+1 are read while the MFMAs of tap t run
-        half8 fa[2][2][2], fb[2][NT][2];            // [buffer][tile][hi, lo]
-        auto load_frags = [&](int buf, int tap) {
-            const int toff = ((tap / 3) * a.PW + (tap % 3)) * kRec;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                fa[buf][mt][0] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff);
-                fa[buf][mt][1] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff + 32);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                fb[buf][nt][0] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase);
-                fb[buf][nt][1] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase + 32);
-            }
-        };
-        load_frags(0, 0);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int cur = tap & 1;
-            if (tap + 1 < 9) load_frags(cur ^ 1, tap + 1);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][1], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][1], acc_c[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        } else {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3) * a.PW + (tap % 3)) * kRec;
-            half8 ah[2], al[2], bh[NT], bl[NT];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff + 32);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bh[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) ah[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + toff);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bl[nt] = *reinterpret_cast<const half8*>(sB + (tap * BN + nt * 32) * kRec + bbase + 32);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
-        }
-        }
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
+        split_mfma_chunk_s1<BN>(sA, sB, abase, bbase, a, acc_t);
     }
 
-    split_epilogue<BN, float>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
+    split_epilogue_one<BN, float>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
             for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
     }
 
-    split_epilogue<BN, float>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
+    split_epilogue_one<BN, float>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
 }
 
 }  // namespace ts2d

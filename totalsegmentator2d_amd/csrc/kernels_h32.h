@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_h32(const ConvArgs a) {
         __builtin_amdgcn_s_setprio(0);
     }
 
-    split_epilogue<BN, _Float16>(a, acc, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
+    split_epilogue_one<BN, _Float16>(a, acc, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
 }
 
 }  // namespace ts2d
