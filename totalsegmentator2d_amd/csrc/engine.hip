@@ -206,7 +206,7 @@ int build_program(ts2d_engine* e) {
             op.dev_wraw = wo; wo = align_up(wo + (size_t)op.cout * ct * 9, 64);
             op.first_direct = true;
         }
-        if (op.type == OP_CONVT && ct % 32 == 0) {                      // [chunk32][k-step 2][4*Cout][32 halves]
+        if (op.type == OP_CONVT && ct % 32 == 0) {                      // [chunk32][column tile of 64][k-step 2][column][32 halves]
             op.split_ok = true;
             op.dev_wh = wo; wo = align_up(wo + (size_t)(ct / 32) * 2 * 4 * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);
@@ -266,7 +266,8 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                         const float v = w[((size_t)ci * co_n + co) * 4 + ab] * wscale;
                         const uint16_t hi = f32_to_f16(v);
                         const uint16_t lo = f32_to_f16(v - f16_to_f32(hi));
-                        uint16_t* rec = d + (((size_t)chunk * 2 + kk) * N + ab * co_n + co) * 32;
+                        const int n = ab * co_n + co;          // [chunk32][column tile of 64][k-step][column][32 halves]
+                        uint16_t* rec = d + ((((size_t)chunk * (N / 64) + n / 64) * 2 + kk) * 64 + n % 64) * 32;
                         rec[cc] = hi; rec[16 + cc] = lo;
                     }
             }
@@ -707,7 +708,11 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 const size_t smem_t = (size_t)2 * Pt * kRec + (size_t)2 * 64 * kRec;
                 const int grid_t = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
                 TRY(prof_begin(e, op.name, st));
-                if (f16) hipLaunchKernelGGL((convT2x2_f16x3<64, _Float16, 1>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
+                const bool t_one = e->use_one && g.lgNIMG == 0 && (size_t)4 * Ht * Wt * op.cout * 4 < ((size_t)1 << 31);
+                if (t_one) {
+                    if (f16) hipLaunchKernelGGL((convT2x2_f16x3_one<_Float16, 1>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
+                    else hipLaunchKernelGGL((convT2x2_f16x3_one<float, 3>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
+                } else if (f16) hipLaunchKernelGGL((convT2x2_f16x3<64, _Float16, 1>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
                 else hipLaunchKernelGGL((convT2x2_f16x3<64, float, 3>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
