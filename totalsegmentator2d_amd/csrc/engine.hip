@@ -8,6 +8,7 @@
 #include "kernels_f16x3_convt.h"
 #include "kernels_f16x3_pp.h"
 #include "kernels_h32.h"
+#include "kernels_head.h"
 #include "kernels_f16x3_one.h"
 #include "kernels_first.h"
 #include "kernels_sw.h"
@@ -206,6 +207,11 @@ int build_program(ts2d_engine* e) {
             op.dev_wraw = wo; wo = align_up(wo + (size_t)op.cout * ct * 9, 64);
             op.first_direct = true;
         }
+        if (op.type == OP_HEAD && ct == 32 && op.cout <= 32) {          // head_mfma32: [k-step 2][column 32][16 hi | 16 lo] halves
+            op.split_ok = true;
+            op.dev_wh = wo; wo = align_up(wo + 2 * 32 * 16, 64);
+            op.dev_ws = wo; wo = align_up(wo + 1, 64);
+        }
         if (op.type == OP_CONVT && ct % 32 == 0) {                      // [chunk32][column tile of 64][k-step 2][column][32 halves]
             op.split_ok = true;
             op.dev_wh = wo; wo = align_up(wo + (size_t)(ct / 32) * 2 * 4 * op.cout * 16, 64);
@@ -251,6 +257,22 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
     memset(out, 0, e->weight_floats * sizeof(float));
     for (const Op& op : e->ops) {
         if (op.first_direct) memcpy(out + op.dev_wraw, blob + op.blob_w, (size_t)op.cout * op.cin * 9 * sizeof(float));
+        if (op.type == OP_HEAD && op.split_ok) {
+            const int ct = op.cin, co_n = op.cout;          // W[k][c]
+            const float* w = blob + op.blob_w;
+            float mx = 0.f;
+            for (size_t i = 0; i < (size_t)ct * co_n; ++i) mx = std::max(mx, std::fabs(w[i]));
+            const float wscale = (mx > 0.f && std::isfinite(mx)) ? std::exp2(std::floor(std::log2(16383.0f / mx))) : 1.f;
+            out[op.dev_ws] = 1.0f / wscale;
+            uint16_t* d = reinterpret_cast<uint16_t*>(out + op.dev_wh);         // zero-initialised: columns >= K stay 0
+            for (int k = 0; k < co_n; ++k)
+                for (int c = 0; c < ct; ++c) {
+                    const float v = w[(size_t)k * ct + c] * wscale;
+                    const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                    uint16_t* rec = d + ((size_t)(c / 16) * 32 + k) * 32;
+                    rec[c % 16] = hi; rec[16 + c % 16] = lo;
+                }
+        }
         if (op.type == OP_CONVT && op.split_ok) {
             const int ct = op.cin, co_n = op.cout, N = 4 * co_n;
             const float* w = blob + op.blob_w;
@@ -789,7 +811,15 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             const unsigned grid = (unsigned)((ha.total + 255) / 256);
             const size_t smem = ((size_t)256 * (src.C + 1) + (size_t)op.cout * src.C + op.cout) * sizeof(float);
             TRY(prof_begin(e, op.name, st));
-            if (src.C == 32) {
+            const bool hm = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT && e->use_one && src.C == 32 && (H * W) % 32 == 0 && W % 32 == 0;
+            if (hm) {      // matrix-core head (split / f16 modes)
+                ha.wph = wts + op.dev_wh; ha.oscale = wts + op.dev_ws;
+                const int bpw = 16;
+                const long long nblk = ha.total / 32;
+                const unsigned gridm = (unsigned)((nblk + 4 * bpw - 1) / (4 * bpw));
+                if (f16) hipLaunchKernelGGL((head_mfma32<_Float16, 1>), dim3(gridm), dim3(256), 0, st, ha, bpw);
+                else hipLaunchKernelGGL((head_mfma32<float, 3>), dim3(gridm), dim3(256), 0, st, ha, bpw);
+            } else if (src.C == 32) {
                 static bool set32 = false;
                 if (!set32) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<32, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                               HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<32, _Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set32 = true; }

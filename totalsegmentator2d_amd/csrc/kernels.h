@@ -383,6 +383,7 @@ constexpr float kSigmoidHalfThreshold = 0x1.8p-24f;
 struct HeadArgs {
     const float* src; const float* sc; const float* sh;   // raw NHWC [B,H,W,C] + its scale/shift [B,C]
     const float* w; const float* bias;                     // [K][C], [K]
+    const float* wph; const float* oscale;                 // head_mfma32: split-fp16 weight image [ks 2][32][16 hi | 16 lo], 1 / scale
     float* logits; uint32_t* mask;                         // NCHW [B,K,H,W]; [B,K,H,W/32] (either may be nullptr)
     int C, K, HW; long long total;                         // total = B*H*W pixels
     float slope;
