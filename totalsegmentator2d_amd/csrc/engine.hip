@@ -448,10 +448,10 @@ hipError_t launch_one_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
-template <int BN, bool PFS, bool PIPE>
+template <int BN, bool PFS, bool PIPE, typename ST, int NP>
 hipError_t launch_one_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv3x3s2_f16x3_one<BN, PFS, PIPE>;
+    auto kern = conv3x3s2_f16x3_one<BN, PFS, PIPE, ST, NP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -460,10 +460,10 @@ hipError_t launch_one_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStrea
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
-hipError_t launch_one_s2(int bn, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    if (bn == 32) return launch_one_s2_inst<32, false, false>(a, grid, smem, st);
+hipError_t launch_one_s2(bool f16, int bn, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    if (bn == 32) return f16 ? launch_one_s2_inst<32, false, false, _Float16, 1>(a, grid, smem, st) : launch_one_s2_inst<32, false, false, float, 3>(a, grid, smem, st);
     // (measured: prefetching the scale/shift vectors or double-buffering the fragments costs registers and gains nothing here)
-    if (bn == 64) return launch_one_s2_inst<64, false, false>(a, grid, smem, st);
+    if (bn == 64) return f16 ? launch_one_s2_inst<64, false, false, _Float16, 1>(a, grid, smem, st) : launch_one_s2_inst<64, false, false, float, 3>(a, grid, smem, st);
     return hipErrorInvalidConfiguration;
 }
 hipError_t launch_one(int bn, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
@@ -764,11 +764,11 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             const bool img32 = (size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4 < ((size_t)1 << 31);
             const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
             const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32 && !e->use_ws && !e->use_pp;
-            const bool one_s2 = split && !f16 && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;
+            const bool one_s2 = split && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;
             if (one) {     // tile inside one image: lean staging path
                 le = launch_one(bn, ca, grid, smem, st);
             } else if (one_s2) {
-                le = launch_one_s2(bn, ca, grid, smem, st);
+                le = launch_one_s2(f16, bn, ca, grid, smem, st);
             } else if (h32) {     // fp16 storage: 32-channel chunks, one product
                 ca.wph = wts + op.dev_wh32;
                 le = launch_h32(bn, ca, grid, smem, st);

@@ -6,6 +6,7 @@
 // while the weight loads of the chunk stay in flight behind the conversion (the generic kernel drains them with vmcnt(0)).
 #pragma once
 #include "kernels_f16x3.h"
+#include "kernels_h32.h"
 
 namespace ts2d {
 
@@ -265,9 +266,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3_one(const ConvArgs a)
 // ------------------------------------------------------------------------------------------------------------
 // Stride-2 counterpart (the strided-conv downsample): arithmetic and LDS layout of conv3x3s2_f16x3, staging as above.
 // ------------------------------------------------------------------------------------------------------------
-template <int BN, bool PFS, bool PIPE>
+template <int BN, bool PFS, bool PIPE, typename ST = float, int NP = 3>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs a) {
-    constexpr int NT = BN / 32, MAXU = 5;
+    constexpr int NT = BN / 32, MAXU = 5, NL = sizeof(ST) == 4 ? 2 : 1;     // NL: 16-byte loads per unit (8 channels)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
 
     const int bid = blockIdx.x;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
             const int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
             lr = (py * a.PW + ((px & 1) ? PWe + (px >> 1) : (px >> 1))) * kRec8;
             if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) g = (unsigned)(iy * a.Win + ix);
-            else { *reinterpret_cast<uint4*>(sA + lr) = uint4{0u, 0u, 0u, 0u}; *reinterpret_cast<uint4*>(sA + lr + 16) = uint4{0u, 0u, 0u, 0u}; }
+            else { *reinterpret_cast<uint4*>(sA + lr) = uint4{0u, 0u, 0u, 0u}; if (NP == 3) *reinterpret_cast<uint4*>(sA + lr + 16) = uint4{0u, 0u, 0u, 0u}; }
         }
         poff[it] = g; lrec[it] = lr;
     }
@@ -336,12 +337,15 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
     const int nchunks = a.C0 / 8;              // the strided conv never reads a concat
     const size_t img_px = (size_t)a.Hin * a.Win;
     // one buffer descriptor per source tensor, based at this tile's image (wave-uniform)
-    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0) + (size_t)nimg0 * img_px * a.C0, 0, (int)(img_px * a.C0 * 4), 0x00020000);
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<ST*>(reinterpret_cast<const ST*>(a.src0)) + (size_t)nimg0 * img_px * a.C0, 0,
+                                                       (int)(img_px * a.C0 * sizeof(ST)), 0x00020000);
     unsigned vo0[MAXU];                        // per-unit byte offsets (chunk offset goes into the scalar offset)
 #pragma unroll
-    for (int it = 0; it < MAXU; ++it) vo0[it] = poff[it] == ~0u ? 0x80000000u : poff[it] * (unsigned)a.C0 * 4u;
+    for (int it = 0; it < MAXU; ++it) vo0[it] = poff[it] == ~0u ? 0x80000000u : poff[it] * (unsigned)a.C0 * (unsigned)sizeof(ST);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 pv[MAXU][2];                         // raw fp32 patch values of the next chunk (in flight during the MFMAs)
+    u32x4 pv[MAXU][NL];                        // raw patch values of the next chunk (in flight during the MFMAs)
+    const _Float16 slope_h = (_Float16)a.slope;
+    const unsigned slope2 = (unsigned)__builtin_bit_cast(unsigned short, slope_h) * 0x10001u;
     f32x4 nsa = f32x4{1.f, 1.f, 1.f, 1.f}, nsb = nsa, nta = f32x4{0.f, 0.f, 0.f, 0.f}, ntb = nta;   // ... and its scale / shift
 
     const int kper = (nchunks + a.ksplit - 1) / a.ksplit;
@@ -355,10 +359,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
     };
     auto prefetch = [&](int ch) {
 #pragma unroll
-        for (int it = 0; it < MAXU; ++it) {
-            pv[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rs0, vo0[it], ch * 32, 0);
-            pv[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rs0, vo0[it] + 16, ch * 32, 0);
-        }
+        for (int it = 0; it < MAXU; ++it)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) pv[it][l] = __builtin_amdgcn_raw_buffer_load_b128(rs0, vo0[it] + 16 * l, ch * 8 * (int)sizeof(ST), 0);
         if (PFS) load_st(ch);
     };
 
@@ -371,35 +374,41 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
         constexpr int WU = 5 * BN * 4, WIT = (WU + kBlock - 1) / kBlock;
         const uint4* wsrc = reinterpret_cast<const uint4*>(a.wph) + ((size_t)ch * a.n_ctiles + ctile) * (5 * BN * 4);
         uint4 w0, w1, w2, w3, w4;
-#define TS2D_WLOAD(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU)) R = wsrc[idx]; }
+#define TS2D_WLOAD(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU) && (NP == 3 || (idx & 2) == 0)) R = wsrc[idx]; }
         TS2D_WLOAD(0, w0) TS2D_WLOAD(1, w1) TS2D_WLOAD(2, w2) TS2D_WLOAD(3, w3) TS2D_WLOAD(4, w4)
 #undef TS2D_WLOAD
         // ---- patch: InstanceNorm + LeakyReLU on the fly, fp16 in -> fp16 LDS records (padding records stay zero)
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
             if (poff[it] != ~0u) {
-                f32x4 va = __builtin_bit_cast(f32x4, pv[it][0]), vb = __builtin_bit_cast(f32x4, pv[it][1]);
-                if (normed) {
-                    va = va * nsa + nta; vb = vb * nsb + ntb;
+                if constexpr (sizeof(ST) == 4) {
+                    f32x4 va = __builtin_bit_cast(f32x4, pv[it][0]), vb = __builtin_bit_cast(f32x4, pv[it][NL - 1]);
+                    if (normed) {
+                        va = va * nsa + nta; vb = vb * nsb + ntb;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            va[e] = fmaxf(va[e], va[e] * a.slope);     // LeakyReLU (0 < slope < 1)
+                            vb[e] = fmaxf(vb[e], vb[e] * a.slope);
+                        }
+                    }
+                    half8 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        va[e] = fmaxf(va[e], va[e] * a.slope);     // LeakyReLU (0 < slope < 1)
-                        vb[e] = fmaxf(vb[e], vb[e] * a.slope);
+                        const _Float16 ha = (_Float16)va[e], hb = (_Float16)vb[e];
+                        hi[e] = ha; hi[e + 4] = hb;
+                        if (NP == 3) { lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb); }
                     }
+                    *reinterpret_cast<half8*>(sA + lrec[it]) = hi;
+                    if (NP == 3) *reinterpret_cast<half8*>(sA + lrec[it] + 16) = lo;
+                } else {
+                    uint4 x = uint4{pv[it][0][0], pv[it][0][1], pv[it][0][2], pv[it][0][3]};
+                    if (normed) x = norm_lrelu_8(x, nsa, nsb, nta, ntb, slope2);
+                    *reinterpret_cast<uint4*>(sA + lrec[it]) = x;
                 }
-                half8 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const _Float16 ha = (_Float16)va[e], hb = (_Float16)vb[e];
-                    hi[e] = ha; hi[e + 4] = hb;
-                    lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb);
-                }
-                *reinterpret_cast<half8*>(sA + lrec[it]) = hi;
-                *reinterpret_cast<half8*>(sA + lrec[it] + 16) = lo;
             }
         }
         // ---- weight registers -> LDS records [k-step][col][16 hi | 16 lo | pad]
-#define TS2D_WSTORE(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU)) \
+#define TS2D_WSTORE(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU) && (NP == 3 || (idx & 2) == 0)) \
             *reinterpret_cast<uint4*>(sB + (idx >> 2) * kRec + (idx & 3) * 16) = R; }
         TS2D_WSTORE(0, w0) TS2D_WSTORE(1, w1) TS2D_WSTORE(2, w2) TS2D_WSTORE(3, w3) TS2D_WSTORE(4, w4)
 #undef TS2D_WSTORE
@@ -421,12 +430,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 fa[buf][mt][0] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s]);
-                fa[buf][mt][1] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s] + 16);
+                if (NP == 3) fa[buf][mt][1] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s] + 16);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 fb[buf][nt][0] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase);
-                fb[buf][nt][1] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase + 32);
+                if (NP == 3) fb[buf][nt][1] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase + 32);
             }
         };
         load_frags(0, 0);
@@ -438,12 +447,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][1], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0);
+                    { if (NP == 3) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][1], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0); }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][1], acc_c[mt][nt], 0, 0, 0);
+                    { if (NP == 3) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][1], acc_c[mt][nt], 0, 0, 0); }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -456,23 +465,23 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
         for (int s = 0; s < 5; ++s) {
             half8 ah[2], al[2], bh[NT], bl[NT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s] + 16);
+            for (int mt = 0; mt < 2; ++mt) if (NP == 3) al[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s] + 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bh[nt] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) ah[mt] = *reinterpret_cast<const half8*>(sA + abase[mt] + tofl[s]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bl[nt] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase + 32);
+            for (int nt = 0; nt < NT; ++nt) if (NP == 3) bl[nt] = *reinterpret_cast<const half8*>(sB + (s * BN + nt * 32) * kRec + bbase + 32);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+                    { if (NP == 3) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0); }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0);
+                    { if (NP == 3) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0); }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
             for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
     }
 
-    split_epilogue_one<BN, float>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
+    split_epilogue_one<BN, ST>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
 }
 
 }  // namespace ts2d

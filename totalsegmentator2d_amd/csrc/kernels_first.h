@@ -89,6 +89,11 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
     }
 
     float st_s[NT], st_q[NT];
+    // complete one-image tile: one lane offset per 32x32 block + wave-uniform row offsets (see split_epilogue_one)
+    const bool full = a.lgNIMG == 0 && ty0 + TH <= a.H && tx0 + TW <= a.W && a.lgTW >= 4 && nimg0 < a.B;
+    const size_t img_el = (size_t)a.H * a.W * a.Cout;
+    const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0,
+                                                       (int)(full ? img_el * sizeof(ST) : 0), 0x00020000);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 32 + r;
@@ -96,17 +101,32 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
         float ss = 0.f, qq = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+            if (full) {
+                const int m0 = 64 * w + 32 * mt + 4 * h;
+                const int oy = ty0 + (m0 >> a.lgTW), ox = tx0 + (m0 & (TW - 1));
+                const unsigned voff = (unsigned)(((oy * a.W + ox) * a.Cout + co) * (int)sizeof(ST));
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-                const int m = 64 * w + 32 * mt + row;
-                const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
-                const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
-                if (il < NIMG && n < a.B && oy < a.H && ox < a.W) {
+                for (int i = 0; i < 16; ++i) {
+                    const int rowoff = (i & 3) + 8 * (i >> 2);
+                    const unsigned soff = (unsigned)((((rowoff & (TW - 1)) + (rowoff >> a.lgTW) * a.W) * a.Cout) * (int)sizeof(ST));
                     float v = acc[mt][nt][i] + bv;
-                    store_act<ST>(a.dst, ((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + co, v);
+                    buffer_store_act<ST>(v, rsd, voff, soff);
                     v = round_act<ST>(v);
                     ss += v; qq += v * v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const int m = 64 * w + 32 * mt + row;
+                    const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+                    const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
+                    if (il < NIMG && n < a.B && oy < a.H && ox < a.W) {
+                        float v = acc[mt][nt][i] + bv;
+                        store_act<ST>(a.dst, ((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + co, v);
+                        v = round_act<ST>(v);
+                        ss += v; qq += v * v;
+                    }
                 }
             }
         }
