@@ -720,11 +720,14 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             ca.lgTH = g.lgTH; ca.lgTW = g.lgTW; ca.lgNIMG = g.lgNIMG; ca.tiles_x = g.tiles_x; ca.tiles_y = g.tiles_y;
             const int bn = (ca.N % 64 == 0 && op.cout % 64 == 0) ? 64 : 32;
             ca.n_mtiles = g.n_mtiles; ca.n_ctiles = ca.N / bn; ca.PH = g.PH; ca.PW = g.PW; ca.slope = a.leaky_slope;
+            auto lg_exact = [](int v) { return (v > 0 && (v & (v - 1)) == 0) ? ilog2(v) : -1; };
+            ca.lg_tx = lg_exact(g.tiles_x); ca.lg_tpi = lg_exact(g.tiles_x * g.tiles_y); ca.lg_nct = lg_exact(ca.n_ctiles);
             const int P = (g.PH * g.PW) << g.lgNIMG;
             const bool split = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT;
             if (f16 && !split) return fail(TS2D_ERR_INVALID, "op %s has no fp16 kernel (channel counts must be multiples of 16)", op.name.c_str());
             if (split && !conv) {
                 ca.n_ctiles = ca.N / 64;                       // N = 4 * Cout is a multiple of 128; each 32-column tile lies in one (a,b) tap
+                ca.lg_nct = lg_exact(ca.n_ctiles);
                 ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
                 const int Pt = 1 << (g.lgTH + g.lgTW + g.lgNIMG);
                 const size_t smem_t = (size_t)2 * Pt * kRec + (size_t)2 * 64 * kRec;
