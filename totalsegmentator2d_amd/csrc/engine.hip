@@ -4,9 +4,7 @@
 #include "../../include/ts2d_engine.h"
 #include "kernels.h"
 #include "kernels_f16x3.h"
-#include "kernels_f16x3_ws.h"
 #include "kernels_f16x3_convt.h"
-#include "kernels_f16x3_pp.h"
 #include "kernels_h32.h"
 #include "kernels_head.h"
 #include "kernels_f16x3_one.h"
@@ -87,12 +85,9 @@ struct ts2d_engine {
     float* d_weights = nullptr; size_t weight_floats = 0;
     bool weights_ready = false;
     int precision = TS2D_PRECISION_F32_SPLIT_F16X3;
-    bool use_ws = false;          // warp-specialised persistent split kernel: opt-in experiment (TS2D_WS=1); measured
-                                  // slower than two independent 256-thread workgroups per CU in round 1
     int num_cus = 256;
     bool use_h32 = true;          // precision mode f16: 32-channel-chunk kernel (TS2D_H32=0 falls back to the 16-channel one)
     bool use_one = true;          // one-image-tile split kernel (TS2D_ONE=0 falls back to the generic one)
-    bool use_pp = false;          // ping-pong split kernel: opt-in experiment (TS2D_PP=1); measured slower in round 1
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
     float* d_part = nullptr;
@@ -503,46 +498,6 @@ hipError_t launch_split_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStr
     return hipGetLastError();
 }
 
-template <int BN>
-hipError_t launch_split_ws_inst(const ConvArgs& a, int n_virtual, int grid, size_t smem, hipStream_t st) {
-    static bool attr_set = false;
-    auto kern = conv3x3_f16x3_ws<BN>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWsThreads), smem, st, a, n_virtual);
-    return hipGetLastError();
-}
-
-hipError_t launch_split_ws(int bn, const ConvArgs& a, int n_virtual, int grid, size_t smem, hipStream_t st) {
-    if (bn == 32) return launch_split_ws_inst<32>(a, n_virtual, grid, smem, st);
-    if (bn == 64) return launch_split_ws_inst<64>(a, n_virtual, grid, smem, st);
-    return hipErrorInvalidConfiguration;
-}
-
-template <int BN, int MAXU>
-hipError_t launch_split_pp_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    static bool attr_set = false;
-    auto kern = conv3x3_f16x3_pp<BN, MAXU>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_split_pp(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    if (bn == 32 && maxu == 3) return launch_split_pp_inst<32, 3>(a, grid, smem, st);
-    if (bn == 32 && maxu == 5) return launch_split_pp_inst<32, 5>(a, grid, smem, st);
-    if (bn == 64 && maxu == 3) return launch_split_pp_inst<64, 3>(a, grid, smem, st);
-    if (bn == 64 && maxu == 5) return launch_split_pp_inst<64, 5>(a, grid, smem, st);
-    return hipErrorInvalidConfiguration;
-}
-
 template <typename ST, int NP>
 hipError_t launch_split_s2_t(int bn, int maxu, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
     if (bn == 32 && maxu == 5) return launch_split_s2_inst<32, 5, ST, NP>(a, grid, smem, st);
@@ -750,7 +705,7 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 smem = std::max(smem, (size_t)4 * bn * 2 * sizeof(float));
                 ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
             }
-            const int ksplit = (split && !e->use_ws && !e->use_pp) ? choose_ksplit(e, op, B, H, W) : 1;
+            const int ksplit = split ? choose_ksplit(e, op, B, H, W) : 1;
             if (ksplit > 1) {
                 ca.ksplit = ksplit; ca.kslice_stride = (long long)B * Ht * Wt * op.cout;
                 ca.dst = e->d_partial; ca.part = nullptr;
@@ -758,15 +713,11 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             if (smem > 160 * 1024) return fail(TS2D_ERR_INVALID, "op %s: LDS tile of %zu bytes exceeds 160 KiB", op.name.c_str(), smem);
             const int grid = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
             TRY(prof_begin(e, op.name, st));
-            // warp-specialised persistent kernel: stride 1, tile inside one image, patch <= 384 pixels
-            const bool ws = split && !f16 && stride == 1 && g.lgNIMG == 0 && P <= 384 && e->use_ws;
             hipError_t le;
-            const size_t smem_pp = 2 * ((size_t)P * kRec + (size_t)9 * bn * kRec) + (size_t)2 * 4 * bn * 2 * sizeof(float);
-            const bool pp = split && !f16 && stride == 1 && !ws && e->use_pp && smem_pp <= 160 * 1024;
             // (both one-image kernels address a source image through a 32-bit buffer offset)
             const bool img32 = (size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4 < ((size_t)1 << 31);
             const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
-            const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32 && !e->use_ws && !e->use_pp;
+            const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32;
             const bool one_s2 = split && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;
             if (one) {     // tile inside one image: lean staging path
                 le = launch_one(bn, ca, grid, smem, st);
@@ -775,12 +726,6 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             } else if (h32) {     // fp16 storage: 32-channel chunks, one product
                 ca.wph = wts + op.dev_wh32;
                 le = launch_h32(bn, ca, grid, smem, st);
-            } else if (pp) {      // ping-pong kernel: two pixel tiles per 512-thread workgroup in enforced anti-phase
-                const int n_pairs = (g.n_mtiles + 1) / 2;
-                le = launch_split_pp(bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, (n_pairs + 7) / 8 * 8 * ca.n_ctiles, smem_pp, st);
-            } else if (ws) {
-                const size_t smem_ws = 2 * ((size_t)P * kRec + (size_t)9 * bn * kRec) + (size_t)4 * bn * 2 * sizeof(float);
-                le = launch_split_ws(bn, ca, grid, std::min(grid, e->num_cus), smem_ws, st);
             } else if (split) {
                 le = stride == 1 ? launch_split(f16, bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, grid, smem, st)
                                  : launch_split_s2(f16, bn, P <= 5 * kBlock ? 5 : 6, ca, grid, smem, st);
@@ -863,11 +808,8 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
-        if (getenv("TS2D_PP")) e->use_pp = getenv("TS2D_PP")[0] == '1';
         if (getenv("TS2D_H32")) e->use_h32 = getenv("TS2D_H32")[0] == '1';
         if (getenv("TS2D_ONE")) e->use_one = getenv("TS2D_ONE")[0] == '1';
-        const char* ws = getenv("TS2D_WS");
-        e->use_ws = ws && ws[0] == '1';
     }
     int rc = build_program(e);
     if (rc != TS2D_OK) { delete e; return rc; }
