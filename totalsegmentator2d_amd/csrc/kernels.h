@@ -23,9 +23,6 @@ constexpr int kBM = 256;      // output pixels per workgroup tile
 // [64w, 64w+64) = 2 MFMA row tiles, all BN columns.  Per Cin chunk of CK channels the (haloed) input patch is
 // staged ONCE into LDS (normalised + activated on the way) and reused by all taps.
 // ------------------------------------------------------------------------------------------------------------
-// x / d for block-uniform x: a shift when d is a power of two (lg >= 0), the expanded integer division otherwise
-__device__ __forceinline__ int div_lg(int x, int d, int lg) { return lg >= 0 ? (x >> lg) : x / d; }
-
 struct ConvArgs {
     const float* src0; const float* sc0; const float* sh0; int C0;   // sc0 == nullptr: identity (no norm/act)
     const float* src1; const float* sc1; const float* sh1; int C1;   // second half of the virtual concat (or C1=0)
@@ -40,7 +37,8 @@ struct ConvArgs {
     int lgTH, lgTW, lgNIMG;
     int tiles_x, tiles_y; // tiles per image
     int n_mtiles, n_ctiles;
-    int lg_nct, lg_tx, lg_tpi;   // log2 of n_ctiles / tiles_x / tiles_x*tiles_y when a power of two, else -1 (one-image kernels)
+    int lg_nct, lg_tx, lg_tpi;   // log2 of n_ctiles / tiles_x / tiles_x*tiles_y when a power of two, else -1 (the one-image kernels
+                                 // decode their block index with shifts and are only launched when all three are >= 0)
     int PH, PW;           // staged patch dims per image
     float slope;
     const void* wph;      // split-fp16 packed weights [chunk][tap][N][16 hi | 16 lo] (f16x3 kernel only)

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3_one(const ConvArgs a
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = bid >> 3;
-    const int qm = div_lg(q8, a.n_ctiles, a.lg_nct);
+    const int qm = q8 >> a.lg_nct;                  // (one-image kernels: power-of-two tilings only, the engine checks)
     const int mtile = qm * 8 + xcd;
     const int ctile = q8 - qm * a.n_ctiles;
     if (mtile >= a.n_mtiles) return;
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3_one(const ConvArgs a
 
     const int TH = 1 << a.lgTH, TW = 1 << a.lgTW;
     const int tpi = a.tiles_x * a.tiles_y;
-    const int nimg0 = div_lg(mtile, tpi, a.lg_tpi), tin = mtile - nimg0 * tpi;
-    const int tyi = div_lg(tin, a.tiles_x, a.lg_tx), txi = tin - tyi * a.tiles_x;
+    const int nimg0 = mtile >> a.lg_tpi, tin = mtile - nimg0 * tpi;
+    const int tyi = tin >> a.lg_tx, txi = tin - tyi * a.tiles_x;
     const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

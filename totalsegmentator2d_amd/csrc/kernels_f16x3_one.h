@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3_one(const ConvArgs a)
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = bid >> 3;
-    const int qm = div_lg(q8, a.n_ctiles, a.lg_nct);
+    const int qm = q8 >> a.lg_nct;                  // (one-image kernels: power-of-two tilings only, the engine checks)
     const int mtile = qm * 8 + xcd;
     const int ctile = q8 - qm * a.n_ctiles;
     if (mtile >= a.n_mtiles) return;
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3_one(const ConvArgs a)
 
     const int TH = 1 << a.lgTH, TW = 1 << a.lgTW;
     const int tpi = a.tiles_x * a.tiles_y;
-    const int nimg0 = div_lg(mtile, tpi, a.lg_tpi), tin = mtile - nimg0 * tpi;
-    const int tyi = div_lg(tin, a.tiles_x, a.lg_tx), txi = tin - tyi * a.tiles_x;
+    const int nimg0 = mtile >> a.lg_tpi, tin = mtile - nimg0 * tpi;
+    const int tyi = tin >> a.lg_tx, txi = tin - tyi * a.tiles_x;
     const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -145,23 +145,6 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3_one(const ConvArgs a)
         }
         poff[it] = g;
     }
-
-    int abase[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = 64 * w + 32 * mt + r;
-        const int ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
-        abase[mt] = (ty * a.PW + tx) * kRec + 16 * h;
-    }
-    const int bbase = r * kRec + 16 * h;
-
-    f32x16 acc_t[2][NT];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
 
     const int nchunks = (a.C0 + a.C1) / 16;
     const size_t img_px = (size_t)a.Hin * a.Win;
@@ -211,6 +194,24 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3_one(const ConvArgs a)
     };
 
     if (kbeg < kend) prefetch(kbeg);
+    // (everything the first loads do not need comes after their issue)
+    int abase[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = 64 * w + 32 * mt + r;
+        const int ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+        abase[mt] = (ty * a.PW + tx) * kRec + 16 * h;
+    }
+    const int bbase = r * kRec + 16 * h;
+
+    f32x16 acc_t[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
+
     for (int ch = kbeg; ch < kend; ++ch) {
         const bool normed = (ch * 16 < a.C0) ? (a.sc0 != nullptr) : (a.sc1 != nullptr);
         __syncthreads();   // the previous chunk's MFMA reads of LDS are done
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = bid >> 3;
-    const int qm = div_lg(q8, a.n_ctiles, a.lg_nct);
+    const int qm = q8 >> a.lg_nct;                  // (one-image kernels: power-of-two tilings only, the engine checks)
     const int mtile = qm * 8 + xcd;
     const int ctile = q8 - qm * a.n_ctiles;
     if (mtile >= a.n_mtiles) return;
@@ -282,8 +283,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
 
     const int TH = 1 << a.lgTH, TW = 1 << a.lgTW;
     const int tpi = a.tiles_x * a.tiles_y;
-    const int nimg0 = div_lg(mtile, tpi, a.lg_tpi), tin = mtile - nimg0 * tpi;
-    const int tyi = div_lg(tin, a.tiles_x, a.lg_tx), txi = tin - tyi * a.tiles_x;
+    const int nimg0 = mtile >> a.lg_tpi, tin = mtile - nimg0 * tpi;
+    const int tyi = tin >> a.lg_tx, txi = tin - tyi * a.tiles_x;
     const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
