@@ -114,6 +114,11 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
                               const int32_t* tile_y, const int32_t* tile_x, int mirror_mask, const uint16_t* gaussian_f16,
                               uint16_t* logits_f16, uint8_t* seg_u8);
 
+/* 1 if the last ts2d_engine_predict_tiled call produced an infinite aggregated float16 logit - upstream's
+ * "Encountered inf in predicted array" check of predict_sliding_window_return_logits (reached from
+ * ts2d/core/inference/prediction_worker.py:209), evaluated on the device instead of a host pass over the array. */
+int ts2d_engine_tiled_inf_flag(const ts2d_engine* e);
+
 /* Coronal maximum + mean projection of a volume on the device (reference ts2d/tool.py:152-160 -> ts2d/core/util/image.py:46-101).
  *   volume     host pointer to the ORIGINAL contiguous buffer of `n_elems` elements of type `dtype`
  *              (0 = int16, 1 = uint8, 2 = float32, 3 = uint16, 4 = int32)

@@ -79,3 +79,30 @@ def test_device_aggregation_is_bit_identical_to_host_aggregation(name):
     finally:
         dev.close()
     assert a.dtype == b.dtype == np.float16 and np.array_equal(a, b)
+
+
+def test_infinite_aggregated_logit_is_detected_on_the_device():
+    """Upstream raises 'Encountered inf in predicted array' after the fp16 aggregation; the engine evaluates that predicate in
+    sw_aggregate (ts2d_engine_tiled_inf_flag).  A head bias beyond the float16 range forces it."""
+    from totalsegmentator2d_amd import weights
+    arch, shape, patch, step, mirror, folds, seed = cases.SW_CASES['sw_2tiles_mirror']
+    sd, blob = blob_for(arch, seed)
+    data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
+    p = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=True)
+    p.manual_initialization(arch, [blob], patch, inference_allowed_mirroring_axes=mirror)
+    try:
+        p.predict_logits_from_preprocessed_data(data)
+        assert p.engines[0].last_tiled_inf is False
+    finally:
+        p.close()
+    sd = dict(sd)
+    key = [k for k in sd if 'seg_layers' in k and k.endswith('bias')][-1]
+    sd[key] = np.full_like(sd[key], 1e6)                       # > 65504: every aggregated logit overflows float16
+    p = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=True)
+    p.manual_initialization(arch, [weights.pack_blob(arch, sd)], patch, inference_allowed_mirroring_axes=mirror)
+    try:
+        with pytest.raises(RuntimeError, match='Encountered inf'):
+            p.predict_logits_from_preprocessed_data(data)
+        assert p.engines[0].last_tiled_inf is True
+    finally:
+        p.close()

@@ -58,3 +58,21 @@ def test_pad_and_mirror_combos():
     assert rev[2] == slice(1, 6) and rev[3] == slice(0, 7)                       # below = diff // 2
     assert sw.mirror_combos((0, 1)) == [(), (2,), (3,), (2, 3)] and sw.mirror_combos(None) == [()]
     assert sw.tile_slicers((644, 512), (512, 512), 0.5, 1) == [(0, 0, 0), (0, 132, 0)]
+
+
+def test_fp16_threshold_and_inf_predicates_match_the_float_definitions_exhaustively():
+    """export.py thresholds fp16 logits and predictor.py tests them for inf on the BIT PATTERN; both must equal the float
+    definitions (sigmoid(float32(x)) > 0.5, isinf(x)) on every one of the 65536 half-precision values."""
+    import torch
+    from totalsegmentator2d_amd.export import convert_predicted_logits_to_segmentation_with_correct_shape
+    from totalsegmentator2d_amd.predictor import _any_inf_f16
+    v = np.arange(65536, dtype=np.uint32).astype(np.uint16)
+    x = v.view(np.float16).reshape(1, 1, 256, 256)
+    props = {'shape_before_cropping': (1, 256, 256), 'bbox_used_for_cropping': [[0, 1], [0, 256], [0, 256]]}
+    seg = convert_predicted_logits_to_segmentation_with_correct_shape(x, props, True)
+    with np.errstate(all='ignore'):
+        ref = (torch.sigmoid(torch.from_numpy(x.copy()).float()) > 0.5).numpy().astype(np.uint8)
+    assert np.array_equal(seg, ref)
+    assert _any_inf_f16(x)
+    finite = x.copy(); finite[np.isinf(finite)] = 1.0
+    assert not _any_inf_f16(finite)                       # NaNs alone are not "inf"

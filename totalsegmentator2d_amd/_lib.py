@@ -20,7 +20,7 @@ PRECISION_F16 = 2
 
 # every symbol include/ts2d_engine.h declares
 SYMBOLS = ('ts2d_engine_create', 'ts2d_engine_load_weights', 'ts2d_engine_weight_buffer', 'ts2d_engine_weights_ready',
-           'ts2d_engine_forward', 'ts2d_engine_predict_tiled', 'ts2d_project_coronal', 'ts2d_engine_reserve', 'ts2d_engine_set_precision', 'ts2d_engine_set_profiling', 'ts2d_engine_num_ops',
+           'ts2d_engine_forward', 'ts2d_engine_predict_tiled', 'ts2d_engine_tiled_inf_flag', 'ts2d_project_coronal', 'ts2d_engine_reserve', 'ts2d_engine_set_precision', 'ts2d_engine_set_profiling', 'ts2d_engine_num_ops',
            'ts2d_engine_op_name', 'ts2d_engine_op_times', 'ts2d_engine_debug_tensor', 'ts2d_engine_device_bytes', 'ts2d_engine_destroy',
            'ts2d_last_error', 'ts2d_abi_version')
 
@@ -97,6 +97,8 @@ def load():
     lib.ts2d_engine_op_times.argtypes = [c.c_void_p, c.c_void_p, c.c_int]
     lib.ts2d_engine_debug_tensor.restype = c.c_int
     lib.ts2d_engine_debug_tensor.argtypes = [c.c_void_p, c.c_char_p, c.c_void_p, c.c_size_t, c.POINTER(c.c_int32 * 4)]
+    lib.ts2d_engine_tiled_inf_flag.restype = c.c_int
+    lib.ts2d_engine_tiled_inf_flag.argtypes = [c.c_void_p]
     lib.ts2d_engine_device_bytes.restype = c.c_size_t
     lib.ts2d_engine_device_bytes.argtypes = [c.c_void_p]
     lib.ts2d_engine_destroy.restype = c.c_int

@@ -86,6 +86,7 @@ struct ts2d_engine {
     bool weights_ready = false;
     int precision = TS2D_PRECISION_F32_SPLIT_F16X3;
     int num_cus = 256;
+    int tiled_inf = 0;            // the last predict_tiled produced an infinite aggregated logit (ts2d_engine_tiled_inf_flag)
     bool use_h32 = true;          // precision mode f16: 32-channel-chunk kernel (TS2D_H32=0 falls back to the 16-channel one)
     bool use_one = true;          // one-image-tile split kernel (TS2D_ONE=0 falls back to the generic one)
     // workspace
@@ -914,7 +915,7 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
     const size_t o_img = take((size_t)C * Hp * Wp * 4), o_batch = take((size_t)rows * C * ph * pw * 4);
     const size_t o_log = take((size_t)rows * K * ph * pw * 4), o_g = take((size_t)ph * pw * 2);
     const size_t o_o16 = take((size_t)K * Hp * Wp * 2), o_seg = take((size_t)K * Hp * Wp);
-    const size_t o_ty = take((size_t)n_tiles * 4), o_tx = take((size_t)n_tiles * 4), o_vf = take(16);
+    const size_t o_ty = take((size_t)n_tiles * 4), o_tx = take((size_t)n_tiles * 4), o_vf = take(16), o_flag = take(4);
     if (off > e->sw_bytes) {
         HIP_TRY(hipStreamSynchronize(st));
         if (e->d_sw) { HIP_TRY(hipFree(e->d_sw)); e->d_sw = nullptr; e->sw_bytes = 0; }
@@ -929,6 +930,8 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
     HIP_TRY(hipMemcpyAsync(d_img, image, (size_t)C * Hp * Wp * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_ty, tile_y, (size_t)n_tiles * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_tx, tile_x, (size_t)n_tiles * 4, hipMemcpyHostToDevice, st));
+    int* d_flag = reinterpret_cast<int*>(b + o_flag);
+    HIP_TRY(hipMemsetAsync(d_flag, 0, 4, st));
     HIP_TRY(hipMemcpyAsync(d_vf, vflip, 16, hipMemcpyHostToDevice, st));
     if (gaussian_f16) HIP_TRY(hipMemcpyAsync(d_g, gaussian_f16, (size_t)ph * pw * 2, hipMemcpyHostToDevice, st));
     {
@@ -944,14 +947,18 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
         const long long total = (long long)K * Hp * Wp;
         hipLaunchKernelGGL(sw_aggregate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_log, K, Hp, Wp, ph, pw, n_tiles, V,
                            d_ty, d_tx, d_vf, gaussian_f16 ? d_g : nullptr, logits_f16 ? d_o16 : nullptr, seg_u8 ? d_seg : nullptr,
-                           kSigmoidHalfThreshold, total);
+                           kSigmoidHalfThreshold, total, d_flag);
         HIP_TRY(hipGetLastError());
     }
+    e->tiled_inf = 0;
+    HIP_TRY(hipMemcpyAsync(&e->tiled_inf, d_flag, 4, hipMemcpyDeviceToHost, st));
     if (logits_f16) HIP_TRY(hipMemcpyAsync(logits_f16, d_o16, (size_t)K * Hp * Wp * 2, hipMemcpyDeviceToHost, st));
     if (seg_u8) HIP_TRY(hipMemcpyAsync(seg_u8, d_seg, (size_t)K * Hp * Wp, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return TS2D_OK;
 }
+
+int ts2d_engine_tiled_inf_flag(const ts2d_engine* e) { return e ? (e->tiled_inf != 0) : 0; }
 
 int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
                          long long sy, long long sx, long long base, float* out_max, float* out_mean) {

@@ -32,7 +32,7 @@ __device__ __forceinline__ __half h_div(__half a, __half b) { return __float2hal
 __global__ void sw_aggregate(const float* __restrict__ logits, int K, int Hp, int Wp, int ph, int pw, int T, int V,
                              const int* __restrict__ tile_y, const int* __restrict__ tile_x, const int* __restrict__ vflip,
                              const __half* __restrict__ gauss, __half* __restrict__ out16, uint8_t* __restrict__ seg,
-                             float thr, long long total) {
+                             float thr, long long total, int* __restrict__ inf_flag) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int X = (int)(i % Wp); long long r = i / Wp;
@@ -56,6 +56,7 @@ __global__ void sw_aggregate(const float* __restrict__ logits, int K, int Hp, in
         n = h_add(n, g);
     }
     const __half res = h_div(acc, n);
+    if ((__half_as_ushort(res) & 0x7FFFu) == 0x7C00u) *inf_flag = 1;      // upstream's "Encountered inf in predicted array" check
     if (out16) out16[i] = res;
     if (seg) seg[i] = __half2float(res) > thr ? 1 : 0;
 }

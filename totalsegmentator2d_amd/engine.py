@@ -128,7 +128,7 @@ class Engine:
         return (out_logits if logits else None), (out_mask if mask else None)
 
     def predict_tiled(self, image: np.ndarray, patch, tiles, mirror_axes=None, gaussian: Optional[np.ndarray] = None,
-                      want_logits: bool = True, want_seg: bool = False):
+                      want_logits: bool = True, want_seg: bool = False, out_logits: Optional[np.ndarray] = None):
         """Device-side sliding window for one padded 2-D image [C,Hp,Wp] (C-ABI ts2d_engine_predict_tiled).
         tiles: [(y, x), ...] in upstream order; gaussian: float16 [ph,pw] or None.  Returns (float16 [K,Hp,Wp] or None,
         uint8 [K,Hp,Wp] or None)."""
@@ -143,12 +143,15 @@ class Engine:
             mask |= 1 << int(a)
         g = None if gaussian is None else np.ascontiguousarray(gaussian, dtype=np.float16)
         K = self.arch.num_classes
-        out16 = np.empty((K, Hp, Wp), dtype=np.float16) if want_logits else None
+        if out_logits is not None and not (out_logits.dtype == np.float16 and out_logits.shape == (K, Hp, Wp) and out_logits.flags.c_contiguous):
+            raise RuntimeError("out_logits must be a C-contiguous float16 [K,Hp,Wp] array")
+        out16 = (out_logits if out_logits is not None else np.empty((K, Hp, Wp), dtype=np.float16)) if want_logits else None
         seg = np.empty((K, Hp, Wp), dtype=np.uint8) if want_seg else None
         _lib.check(self.lib.ts2d_engine_predict_tiled(
             self._h, image.ctypes.data, Hp, Wp, int(patch[0]), int(patch[1]), len(tiles), ty.ctypes.data, tx.ctypes.data, mask,
             None if g is None else g.ctypes.data, None if out16 is None else out16.ctypes.data,
             None if seg is None else seg.ctypes.data), 'ts2d_engine_predict_tiled')
+        self.last_tiled_inf = bool(self.lib.ts2d_engine_tiled_inf_flag(self._h))     # upstream's inf check, done on the device
         return out16, seg
 
     def _check_shape(self, C, W, mask):

@@ -23,16 +23,22 @@ def convert_predicted_logits_to_segmentation_with_correct_shape(logits, properti
     """[K, Z, H, W] logits (any float dtype) -> uint8 segmentation in the ORIGINAL (pre-crop) array shape:
     multilabel: [K, Z0, H0, W0] of {0,1}; otherwise a label map [Z0, H0, W0] (argmax).  The resampling step of upstream
     is a no-op for the shapes this engine accepts (preprocess.py refuses spacing changes)."""
-    lg = np.asarray(logits).astype(np.float32)
+    lg = np.asarray(logits)
     shape0 = tuple(properties['shape_before_cropping'])
     bbox = properties['bbox_used_for_cropping']
     sl = tuple(slice(b[0], b[1]) for b in bbox)
     if multilabel:
-        seg = (lg > SIGMOID_HALF_THRESHOLD).astype(np.uint8)
+        if lg.dtype == np.float16:
+            # float32(x) > 1.5 * 2^-24 on the fp16 bit pattern: positive, at least the SECOND subnormal (the first, 2^-24, is
+            # below the threshold), +inf included, NaN excluded - the same predicate without a float32 copy of the array
+            v = np.ascontiguousarray(lg).view(np.uint16)
+            seg = ((v >= np.uint16(2)) & (v <= np.uint16(0x7C00))).view(np.uint8)
+        else:
+            seg = (lg.astype(np.float32) > SIGMOID_HALF_THRESHOLD).astype(np.uint8)
         out = np.zeros((lg.shape[0],) + shape0, dtype=np.uint8)
         out[(slice(None),) + sl] = seg
         return out.transpose([0] + [i + 1 for i in transpose_backward])
-    seg = lg.argmax(0).astype(np.uint8)
+    seg = lg.astype(np.float32).argmax(0).astype(np.uint8)
     out = np.zeros(shape0, dtype=np.uint8)
     out[sl] = seg
     return out.transpose(list(transpose_backward))
