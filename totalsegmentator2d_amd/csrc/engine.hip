@@ -717,7 +717,7 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             TRY(prof_begin(e, op.name, st));
             hipError_t le;
             // (both one-image kernels address a source image through a 32-bit buffer offset)
-            const bool img32 = (size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4 < ((size_t)1 << 31) &&
+            const bool img32 = (size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4 < ((size_t)1 << 31) && (size_t)Ht * Wt * op.cout * 4 < ((size_t)1 << 31) &&
                                ca.lg_tx >= 0 && ca.lg_tpi >= 0 && ca.lg_nct >= 0;      // ... and decode power-of-two tilings with shifts
             const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
             const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32;
