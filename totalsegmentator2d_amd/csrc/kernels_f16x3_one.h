@@ -238,16 +238,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3_one(const ConvArgs a)
                         vb[e] = fmaxf(vb[e], vb[e] * a.slope);
                     }
                 }
-                half8 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const _Float16 ha = (_Float16)va[e], hb = (_Float16)vb[e];
-                    hi[e] = ha; hi[e + 4] = hb;
-                    lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb);
-                }
+                uint4 hi, lo;
+                split_hi_lo_8(va, vb, hi, lo);
                 unsigned char* d = sA + (u >> 1) * kRec + (u & 1) * 16;
-                *reinterpret_cast<half8*>(d) = hi;
-                *reinterpret_cast<half8*>(d + 32) = lo;
+                *reinterpret_cast<uint4*>(d) = hi;
+                *reinterpret_cast<uint4*>(d + 32) = lo;
             }
         }
         // ---- weight registers -> LDS records [tap][col][16 hi | 16 lo | pad]
@@ -394,15 +389,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3_one(const ConvArgs 
                             vb[e] = fmaxf(vb[e], vb[e] * a.slope);
                         }
                     }
-                    half8 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const _Float16 ha = (_Float16)va[e], hb = (_Float16)vb[e];
-                        hi[e] = ha; hi[e + 4] = hb;
-                        if (NP == 3) { lo[e] = (_Float16)(va[e] - (float)ha); lo[e + 4] = (_Float16)(vb[e] - (float)hb); }
-                    }
-                    *reinterpret_cast<half8*>(sA + lrec[it]) = hi;
-                    if (NP == 3) *reinterpret_cast<half8*>(sA + lrec[it] + 16) = lo;
+                    uint4 hi, lo;
+                    split_hi_lo_8(va, vb, hi, lo);      // (fp32 storage: NP == 3)
+                    *reinterpret_cast<uint4*>(sA + lrec[it]) = hi;
+                    if (NP == 3) *reinterpret_cast<uint4*>(sA + lrec[it] + 16) = lo;
                 } else {
                     uint4 x = uint4{pv[it][0][0], pv[it][0][1], pv[it][0][2], pv[it][0][3]};
                     if (normed) x = norm_lrelu_8(x, nsa, nsb, nta, ntb, slope2);
