@@ -209,3 +209,23 @@ def test_config3_config5_in_f16():
             lg, mk = e.forward(x, logits=True, mask=True)
         assert np.abs(lg - ref).max() <= F16_MAX and np.sqrt(((lg - ref) ** 2).mean()) <= F16_RMS
         assert (unpack_mask(mk, hw) != O.logits_to_mask(ref).numpy()).mean() <= F16_MASK
+
+
+def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch):
+    """The one-image-tile kernels (conv3x3_f16x3_one, conv3x3s2_f16x3_one, convT2x2_f16x3_one, first-layer fast epilogue) claim
+    the arithmetic and summation order of the generic kernels: every convolution output must be bit-identical with them switched
+    off (TS2D_ONE=0, read when the engine is created).  The head differs by design (matrix-core head vs plain FMA chain)."""
+    arch, B, H, W, seed = cases.SMALL_CASES['net5_128']
+    _, blob = blob_for(arch, seed)
+    x = cases.make_input(arch, B, H, W, seed)
+    names = ['enc0.c0', 'enc0.c1', 'enc1.c0', 'enc2.c1', 'enc4.c1', 'dec3.c0', 'dec1.c1', 'dec0.c0', 'dec0.c1']
+    with Engine(arch, blob) as e:
+        lg1, _ = e.forward(x, logits=True)
+        t1 = {n: e.debug_tensor(n) for n in names}
+    monkeypatch.setenv('TS2D_ONE', '0')
+    with Engine(arch, blob) as e:
+        lg0, _ = e.forward(x, logits=True)
+        t0 = {n: e.debug_tensor(n) for n in names}
+    for n in names:
+        assert np.array_equal(t0[n], t1[n]), n
+    assert np.abs(lg0 - lg1).max() <= 1e-5

@@ -96,11 +96,11 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
                 const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
                 const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
                 if (il < NIMG && n < a.B && oy < a.Ht && ox < a.Wt) {
-                    float v = acc_t[mt][nt][i] * oscale + bv;
+                    float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);      // explicit FMAs: the same rounding in every instantiation
                     const size_t o = ((size_t)(n * a.Ht + oy) * a.Wt + ox) * a.Cout + co;
                     if (a.ksplit > 1) a.dst[(size_t)blockIdx.y * a.kslice_stride + o] = v;          // fp32 partial
                     else { store_act<ST>(a.dst, o, v); v = round_act<ST>(v); }                      // statistics of what is stored
-                    st_s[nt] += v; st_q[nt] += v * v;
+                    st_s[nt] += v; st_q[nt] = __builtin_fmaf(v, v, st_q[nt]);
                 }
             }
         }
@@ -165,10 +165,10 @@ __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&a
             for (int i = 0; i < 16; ++i) {
                 const int rowoff = (i & 3) + 8 * (i >> 2);
                 const unsigned soff = (unsigned)((((rowoff & (TW - 1)) + (rowoff >> a.lgTW) * a.Wt) * a.Cout) * (int)sizeof(ST));   // scalar
-                float v = acc_t[mt][nt][i] * oscale + bv;
+                float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);          // explicit FMAs: the same rounding as split_epilogue
                 buffer_store_act<ST>(v, rs, voff, soff);
                 v = round_act<ST>(v);                                                // statistics of what is stored
-                s += v; q += v * v;
+                s += v; q = __builtin_fmaf(v, v, q);
             }
         }
         st_s[nt] = s; st_q[nt] = q;

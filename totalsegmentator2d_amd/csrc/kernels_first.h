@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
                     float v = acc[mt][nt][i] + bv;
                     buffer_store_act<ST>(v, rsd, voff, soff);
                     v = round_act<ST>(v);
-                    ss += v; qq += v * v;
+                    ss += v; qq = __builtin_fmaf(v, v, qq);
                 }
             } else {
 #pragma unroll
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
                         float v = acc[mt][nt][i] + bv;
                         store_act<ST>(a.dst, ((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + co, v);
                         v = round_act<ST>(v);
-                        ss += v; qq += v * v;
+                        ss += v; qq = __builtin_fmaf(v, v, qq);
                     }
                 }
             }
