@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak (same guide); the split path issues 3 fp16 MFMA products per MAC
+MEASURED_F16_PIPE_TFLOPS = 32768 * 1024 / 20.8e-9 / 1e12      # 32x32x16 MFMA = 32768 FLOP, 1024 SIMDs, 20.8 ns each (probe): ~1613
 PEAK_HBM_GBS = 8000.0
 
 
@@ -199,6 +200,10 @@ def main():
                                'kernel': {'split': 'conv3x3_f16x3_one (18) + conv3x3_f16x3 (4)', 'f16': 'conv3x3_h32 (18) + conv3x3_f16x3<f16> (4)',
                                           'exact': 'conv_mfma_f32<9,1,16,*>'}[args.precision] + f' ({len(per)} launches/step)',
                                'peak_note': ('dense fp16 MFMA 2500 TFLOP/s / 3 products per MAC' if split else 'fp32 MFMA 32x32x2'),
+                               # profiles/r01_mfma_coissue_probe.txt: a bare v_mfma_f32_32x32x16_f16 stream on every SIMD runs at
+                               # 20.5-21 ns per MFMA (= 32 cycles at the ~1.52 GHz this chip sustains under dense matrix load)
+                               'frac_of_measured_matrix_pipe_rate': (round(achieved / (MEASURED_F16_PIPE_TFLOPS / (3.0 if split else 1.0)), 4)
+                                                                     if args.precision in ('split', 'f16') else None),
                                'algorithmic_flop_per_launch_avg': round(conv_flops / len(per)),
                                'kernel_ms_per_launch_avg': round(conv_ms / len(per), 4),
                                'kernel_ms_per_step': round(conv_ms, 3), 'kernel_share_of_step': round(conv_ms / ms_per_step, 4),
