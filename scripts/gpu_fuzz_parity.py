@@ -1,0 +1,43 @@
+"""Randomised parity sweep: small random architectures / shapes / batch sizes, engine (all three modes) vs the torch-CPU oracle.
+Sizes are chosen so that complete and partial pixel tiles, one-image and multi-image tiles, power-of-two and other tilings occur."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import cases
+from totalsegmentator2d_amd import weights, prng
+from totalsegmentator2d_amd.engine import Engine, unpack_mask
+from oracle import torch_oracle as O
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+worst = {'split': 0.0, 'exact': 0.0}
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+for t in range(n):
+    ns = int(rng.integers(2, 6))
+    feats = [32 * int(rng.choice([1, 1, 2])) for _ in range(ns)]
+    for i in range(1, ns): feats[i] = max(feats[i], feats[i - 1]) * int(rng.choice([1, 2])) if feats[i - 1] < 256 else feats[i - 1]
+    feats = [min(f, 256) for f in feats]
+    K = int(rng.integers(1, 27)); cin = int(rng.integers(1, 4))
+    mult = 2 ** (ns - 1)
+    H = mult * int(rng.integers(1, max(2, 160 // mult) + 1)); W = mult * int(rng.integers(1, max(2, 160 // mult) + 1))
+    if (H >> (ns - 1)) * (W >> (ns - 1)) < 2: W *= 2
+    B = int(rng.integers(1, 6))
+    arch = cases.unet(ns, feats, K, cin=cin, nconv=int(rng.integers(1, 3)))
+    sd = weights.synthetic_state_dict(arch, 100 + t); blob = weights.pack_blob(arch, sd)
+    x = prng.normal_f32(200 + t, 1, (B, cin, H, W))
+    ref = O.unet_forward(arch, sd, x).numpy()
+    with Engine(arch, blob) as e:
+        line = f'{t:2d} stages={ns} feats={feats} K={K} cin={cin} B={B} {H}x{W}:'
+        for mode in ('split', 'exact', 'f16'):
+            e.set_precision(mode)
+            lg, mk = e.forward(x, logits=True, mask=(W % 32 == 0))
+            err = float(np.abs(lg - ref).max())
+            if mode != 'f16':
+                worst[mode] = max(worst[mode], err)
+                assert err <= 1e-4, (line, mode, err)
+            else:
+                assert err <= 0.2, (line, mode, err)
+            if mk is not None:
+                assert np.array_equal(unpack_mask(mk, W), (lg > np.float32(1.5 * 2.0 ** -24)).astype(np.uint8)), (line, mode, 'mask')
+            line += f' {mode} {err:.2e}'
+        print(line, flush=True)
+print('worst', worst)

@@ -229,3 +229,47 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
     for n in names:
         assert np.array_equal(t0[n], t1[n]), n
     assert np.abs(lg0 - lg1).max() <= 1e-5
+
+
+def test_randomised_shapes_against_the_torch_oracle():
+    """A fixed-seed slice of scripts/gpu_fuzz_parity.py: random small architectures, channel counts, batch sizes and ragged
+    extents (complete and partial pixel tiles, one- and multi-image tiles, power-of-two and other tilings), all three modes."""
+    from oracle import torch_oracle as O
+    from totalsegmentator2d_amd import weights, prng
+    rng = np.random.default_rng(7)
+    for t in range(8):
+        ns = int(rng.integers(2, 5))
+        feats = [32]
+        for _ in range(1, ns):
+            feats.append(min(feats[-1] * int(rng.choice([1, 2])), 128))
+        K = int(rng.integers(1, 27)); cin = int(rng.integers(1, 4)); mult = 2 ** (ns - 1)
+        H = mult * int(rng.integers(1, 96 // mult + 1)); W = mult * int(rng.integers(2, 128 // mult + 1))
+        B = int(rng.integers(1, 5))
+        arch = cases.unet(ns, feats, K, cin=cin, nconv=int(rng.integers(1, 3)))
+        sd = weights.synthetic_state_dict(arch, 300 + t)
+        x = prng.normal_f32(400 + t, 1, (B, cin, H, W))
+        ref = O.unet_forward(arch, sd, x).numpy()
+        with Engine(arch, weights.pack_blob(arch, sd)) as e:
+            for mode, tol in (('split', TOL), ('exact', TOL), ('f16', 0.2)):
+                e.set_precision(mode)
+                lg, mk = e.forward(x, logits=True, mask=(W % 32 == 0))
+                assert np.abs(lg - ref).max() <= tol, (t, mode, feats, K, cin, B, H, W)
+                if mk is not None:
+                    assert np.array_equal(unpack_mask(mk, W), _oracle_mask(lg)), (t, mode)
+
+
+def test_short_wide_images_get_one_image_per_tile():
+    """Regression (found by scripts/gpu_fuzz_parity.py): at a level where the image is shorter than 8 rows but wider than 32
+    columns (8x120 input, 4 stages -> 4x60, 2x30, 1x15) a tile of TH x 32 < 256 pixels must still hold ONE image."""
+    from oracle import torch_oracle as O
+    from totalsegmentator2d_amd import weights, prng
+    arch = cases.unet(4, (64, 64, 128, 256), 19, cin=2, nconv=2)
+    sd = weights.synthetic_state_dict(arch, 119)
+    for B, H, W in ((1, 8, 120), (3, 16, 200)):
+        x = prng.normal_f32(219, 1, (B, 2, H, W))
+        ref = O.unet_forward(arch, sd, x).numpy()
+        with Engine(arch, weights.pack_blob(arch, sd)) as e:
+            for mode, tol in (('split', TOL), ('exact', TOL), ('f16', 0.2)):
+                e.set_precision(mode)
+                lg, _ = e.forward(x, logits=True)
+                assert np.isfinite(lg).all() and np.abs(lg - ref).max() <= tol, (mode, B, H, W)

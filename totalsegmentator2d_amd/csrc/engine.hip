@@ -372,6 +372,8 @@ TileGeom tile_geom(int B, int Ht, int Wt, int stride, int taps) {
     const int TW = std::min(32, pow2ceil(Wt));
     const int TH = std::min(pow2ceil(Ht), kBM / TW);
     int NIMG = std::min(16, kBM / (TH * TW));
+    if (Wt > TW || Ht > TH) NIMG = 1;     // several images share a tile only when a whole image fits in it; a short, wide image
+                                          // (Ht < 8 at some level, Wt > 32) gets tiles of TH x 32 < 256 pixels and idle tile rows
     g.lgTH = ilog2(TH); g.lgTW = ilog2(TW); g.lgNIMG = ilog2(NIMG);
     if (NIMG > 1) { g.tiles_x = 1; g.tiles_y = 1; }
     else { g.tiles_x = (Wt + TW - 1) / TW; g.tiles_y = (Ht + TH - 1) / TH; }
@@ -690,7 +692,7 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 const int grid_t = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
                 TRY(prof_begin(e, op.name, st));
                 const bool t_one = e->use_one && g.lgNIMG == 0 && (size_t)4 * Ht * Wt * op.cout * 4 < ((size_t)1 << 31) &&
-                                   ca.lg_tx >= 0 && ca.lg_tpi >= 0 && ca.lg_nct >= 0;
+                                   ca.lg_tx >= 0 && ca.lg_tpi >= 0 && ca.lg_nct >= 0 && g.lgTH + g.lgTW == 8;
                 if (t_one) {
                     if (f16) hipLaunchKernelGGL((convT2x2_f16x3_one<_Float16, 1>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
                     else hipLaunchKernelGGL((convT2x2_f16x3_one<float, 3>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
@@ -718,7 +720,8 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
             hipError_t le;
             // (both one-image kernels address a source image through a 32-bit buffer offset)
             const bool img32 = (size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4 < ((size_t)1 << 31) && (size_t)Ht * Wt * op.cout * 4 < ((size_t)1 << 31) &&
-                               ca.lg_tx >= 0 && ca.lg_tpi >= 0 && ca.lg_nct >= 0;      // ... and decode power-of-two tilings with shifts
+                               ca.lg_tx >= 0 && ca.lg_tpi >= 0 && ca.lg_nct >= 0 &&      // ... and decode power-of-two tilings with shifts
+                               g.lgTH + g.lgTW == 8;                                    // ... of complete 256-pixel tiles
             const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
             const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32;
             const bool one_s2 = split && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;

@@ -144,7 +144,7 @@ __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&a
                                                    int n0col, int nimg0, int ty0, int tx0, int tpi, int tin) {
     constexpr int NT = BN / 32;
     const int TH = 1 << a.lgTH, TW = 1 << a.lgTW;
-    const bool full = a.ksplit == 1 && ty0 + TH <= a.Ht && tx0 + TW <= a.Wt && a.lgTW >= 4 && nimg0 < a.B;     // wave-uniform
+    const bool full = a.ksplit == 1 && a.lgTH + a.lgTW == 8 && ty0 + TH <= a.Ht && tx0 + TW <= a.Wt && a.lgTW >= 4 && nimg0 < a.B;     // wave-uniform
     if (!full) { split_epilogue<BN, ST>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const float oscale = *a.oscale;

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3_one(const ConvArgs a
     }
 
     const float oscale = *a.oscale;
-    const bool full = ty0 + TH <= a.Ht && tx0 + TW <= a.Wt && a.lgTW >= 4;     // wave-uniform
+    const bool full = a.lgTH + a.lgTW == 8 && ty0 + TH <= a.Ht && tx0 + TW <= a.Wt && a.lgTW >= 4;     // wave-uniform
     const size_t out_el = (size_t)4 * a.Ht * a.Wt * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * out_el, 0, (int)(out_el * sizeof(ST)), 0x00020000);
 #pragma unroll

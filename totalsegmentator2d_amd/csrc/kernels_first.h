@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
 
     float st_s[NT], st_q[NT];
     // complete one-image tile: one lane offset per 32x32 block + wave-uniform row offsets (see split_epilogue_one)
-    const bool full = a.lgNIMG == 0 && ty0 + TH <= a.H && tx0 + TW <= a.W && a.lgTW >= 4 && nimg0 < a.B;
+    const bool full = a.lgNIMG == 0 && a.lgTH + a.lgTW == 8 && ty0 + TH <= a.H && tx0 + TW <= a.W && a.lgTW >= 4 && nimg0 < a.B;
     const size_t img_el = (size_t)a.H * a.W * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0,
                                                        (int)(full ? img_el * sizeof(ST) : 0), 0x00020000);
