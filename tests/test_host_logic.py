@@ -76,3 +76,26 @@ def test_fp16_threshold_and_inf_predicates_match_the_float_definitions_exhaustiv
     assert _any_inf_f16(x)
     finite = x.copy(); finite[np.isinf(finite)] = 1.0
     assert not _any_inf_f16(finite)                       # NaNs alone are not "inf"
+
+
+def test_randomised_window_configurations_match_the_torch_pipeline():
+    """Fixed-seed random extents / patch sizes / step sizes / mirror axes / folds / Z: the numpy fp16 aggregation of predictor.py
+    must equal torch's half arithmetic in the oracle pipeline bit for bit (same per-tile network outputs)."""
+    rng = np.random.default_rng(3)
+    for t in range(5):
+        ns = int(rng.integers(2, 4)); mult = 2 ** (ns - 1)
+        feats = [32] + [int(rng.choice([32, 64])) for _ in range(ns - 1)]
+        K = int(rng.integers(1, 6)); cin = int(rng.integers(1, 3))
+        patch = (mult * int(rng.integers(4, 12)), mult * int(rng.integers(4, 12)))
+        Z = int(rng.choice([1, 1, 2]))
+        shape = (Z, int(rng.integers(patch[0] // 2, 3 * patch[0])), int(rng.integers(patch[1] // 2, 3 * patch[1])))
+        step = float(rng.choice([0.5, 0.75, 1.0, 0.3])); mirror = [None, (0,), (1,), (0, 1)][int(rng.integers(0, 4))]
+        folds = int(rng.choice([1, 2]))
+        arch = cases.unet(ns, feats, K, cin=cin)
+        sds = [weights.synthetic_state_dict(arch, 700 + 10 * t + f) for f in range(folds)]
+        data = prng.normal_f32(800 + t, 999, (cin,) + shape)
+        p = _predictor(arch, sds, patch, step, mirror)
+        out = p.predict_logits_from_preprocessed_data(data)
+        out = out.cpu().numpy() if hasattr(out, 'cpu') else out
+        ref = O.predict_logits(arch, sds, data, patch, step, mirror).numpy()
+        assert out.dtype == np.float16 and np.array_equal(out, ref), (t, feats, shape, patch, step, mirror, folds)
