@@ -273,3 +273,23 @@ def test_short_wide_images_get_one_image_per_tile():
                 e.set_precision(mode)
                 lg, _ = e.forward(x, logits=True)
                 assert np.isfinite(lg).all() and np.abs(lg - ref).max() <= tol, (mode, B, H, W)
+
+
+def test_torch_tensors_are_ordered_with_the_callers_stream():
+    """Engine.forward on torch CUDA tensors must be ordered with the caller's torch work without an explicit synchronise:
+    the outputs are consumed by torch ops on the default stream right after the call (found by a soak script that cloned the
+    logits without synchronising)."""
+    import torch
+    arch = UNetArch.canonical()
+    _, blob = blob_for(arch, 1)
+    x = torch.randn(24, 2, 512, 512, device='cuda')
+    with Engine(arch, blob) as e:
+        a, _ = e.forward(x, logits=True)
+        torch.cuda.synchronize()
+        ref = a.clone()
+        for _ in range(3):
+            x2 = x * 1.0                               # producer on the default stream, consumed by the engine
+            b, _ = e.forward(x2, logits=True)
+            got = b.clone()                            # consumer on the default stream, no synchronise in between
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref)

@@ -109,11 +109,28 @@ class Engine:
                 out_logits = torch.empty((B, K, H, W), dtype=torch.float32, device=x.device)
             if mask and out_mask is None:
                 out_mask = torch.empty((B, K, H, W // 32), dtype=torch.int32, device=x.device)
+            side = None
             if stream == 0:
-                stream = torch.cuda.current_stream(x.device).cuda_stream
+                # Order the kernels with the caller's torch work.  A non-default current stream is used directly; torch's DEFAULT
+                # stream has the null handle, which the C-ABI reads as "the engine's own stream" - so run on a side stream that
+                # waits for the current stream and make the current stream wait for it afterwards (no host synchronisation).
+                cur = torch.cuda.current_stream(x.device)
+                if cur.cuda_stream != 0:
+                    stream = cur.cuda_stream
+                else:
+                    if getattr(self, '_side_stream', None) is None:
+                        self._side_stream = torch.cuda.Stream(device=x.device)
+                    side = self._side_stream
+                    side.wait_stream(cur)
+                    stream = side.cuda_stream
+                    for t in (x, out_logits if logits else None, out_mask if mask else None):
+                        if t is not None:
+                            t.record_stream(side)
             _lib.check(self.lib.ts2d_engine_forward(
                 self._h, x.data_ptr(), B, H, W, out_logits.data_ptr() if logits else None,
                 out_mask.data_ptr() if mask else None, 1, ctypes.c_void_p(stream)), 'ts2d_engine_forward')
+            if side is not None:
+                torch.cuda.current_stream(x.device).wait_stream(side)
             return (out_logits if logits else None), (out_mask if mask else None)
         x = np.ascontiguousarray(x, dtype=np.float32)
         B, C, H, W = x.shape
