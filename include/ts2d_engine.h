@@ -106,13 +106,22 @@ int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W,
  *   tile_y/tile_x  host, n_tiles tile origins in upstream order (compute_steps_for_sliding_window)
  *   mirror_mask    bit 0: mirror spatial axis 0 (H), bit 1: axis 1 (W); variants run in upstream order H, W, HW
  *   gaussian_f16   host [patch_h, patch_w] IEEE half bits (compute_gaussian), or NULL for no weighting
- *   logits_f16     host [K, Hp, Wp] half bits: aggregated logits / n_predictions, bit-identical to upstream's float16
- *                  accumulation; may be NULL
+ *   logits_f16     host [K, Hp, Wp] half bits: aggregated logits / n_predictions in upstream's float16 buffers (rounding
+ *                  order: ts2d_engine_set_tile_dtype; equal bit for bit to the repo's ATen-pinned oracle); may be NULL
  *   seg_u8         host [K, Hp, Wp]: sigmoid(float(logit)) > 0.5 of the aggregated logits (multilabel export); may be NULL
  * All tiles x mirror variants go through the network as one batch (chunks of at most 64 rows).  Synchronous. */
 int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp, int patch_h, int patch_w, int n_tiles,
                               const int32_t* tile_y, const int32_t* tile_x, int mirror_mask, const uint16_t* gaussian_f16,
                               uint16_t* logits_f16, uint8_t* seg_u8);
+
+/* Blend order of ts2d_engine_predict_tiled (upstream `prediction *= gaussian; predicted_logits[sl] += prediction` with
+ * float16 `predicted_logits`; reached from ts2d/core/inference/prediction_worker.py:209):
+ *   TS2D_TILE_F32 (default) the reference's CPU path (nnu.py:161-163 forces device=cpu, no autocast): the tile prediction is
+ *       fp32, the product is fp32 x float(half gaussian) in fp32, the sum is a float add with ONE rounding into the half buffer;
+ *   TS2D_TILE_F16 the reference's CUDA path (fp16 autocast): the tile is half, the product and the sum each round to half. */
+#define TS2D_TILE_F32 0
+#define TS2D_TILE_F16 1
+int ts2d_engine_set_tile_dtype(ts2d_engine* e, int mode);
 
 /* 1 if the last ts2d_engine_predict_tiled call produced an infinite aggregated float16 logit - upstream's
  * "Encountered inf in predicted array" check of predict_sliding_window_return_logits (reached from

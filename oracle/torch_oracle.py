@@ -150,10 +150,18 @@ def compute_gaussian(tile_size: Sequence[int], sigma_scale: float = 1. / 8, valu
 
 
 def predict_sliding_window(net, data: torch.Tensor, patch: Sequence[int], step: float = 0.5,
-                           mirror_axes: Sequence[int] | None = (0, 1), use_gaussian: bool = True) -> torch.Tensor:
+                           mirror_axes: Sequence[int] | None = (0, 1), use_gaussian: bool = True,
+                           tile_dtype: str = 'float') -> torch.Tensor:
     """``predict_sliding_window_return_logits`` for a 2-D net on ``[C,Z,H,W]`` data: pad to the patch, for every z
     and every (sx, sy) tile: p = A5(x[None])[0]; p *= g; logits[sl] += p; n[sl[1:]] += g; logits /= n; un-pad.
-    Accumulators and the gaussian are float16 exactly as upstream (results_device = cpu)."""
+    Accumulators and the gaussian are float16 exactly as upstream (results_device = cpu).
+
+    ``tile_dtype`` is the dtype the tile prediction ``p`` has when it meets the half buffers:
+      'float' (default) - the reference's CPU path (``nnu.py:161-163`` forces device=cpu, no autocast): ``network(x)`` is
+                fp32, ``.to(results_device)`` moves device only, so ``p *= g`` is fp32 x half -> fp32 and
+                ``logits[sl] += p`` is ONE rounding into the half buffer (ATen computes half += float in float);
+      'half'  - the CUDA path (fp16 autocast): ``p`` is half, so ``p * g`` and ``logits += p`` each round to half.
+    Both orders are written with the plain ATen statements upstream uses, so ATen itself defines the rounding."""
     assert data.ndim == 4
     data, revert = pad_to_patch(data, patch)
     C, Z, H, W = data.shape
@@ -170,10 +178,11 @@ def predict_sliding_window(net, data: torch.Tensor, patch: Sequence[int], step: 
                     K = p.shape[0]
                     logits = torch.zeros((K, Z, H, W), dtype=torch.half)
                     n_pred = torch.zeros((Z, H, W), dtype=torch.half)
-                p = p.to(torch.half)          # prediction = self._internal_maybe_mirror_and_predict(...)[0].to(results_device)
+                # prediction = self._internal_maybe_mirror_and_predict(...)[0].to(results_device): a device move, no cast
+                p = p.to(torch.half) if tile_dtype == 'half' else p.clone()
                 if use_gaussian:
-                    p = p * g
-                logits[:, d, sx:sx + patch[0], sy:sy + patch[1]] += p
+                    p *= g                    # fp32 *= half computes in fp32 ('float'); half *= half rounds to half ('half')
+                logits[:, d, sx:sx + patch[0], sy:sy + patch[1]] += p      # half += float: float add, one cast to half
                 n_pred[d, sx:sx + patch[0], sy:sy + patch[1]] += g
     logits = logits / n_pred
     if torch.any(torch.isinf(logits)):
@@ -182,13 +191,14 @@ def predict_sliding_window(net, data: torch.Tensor, patch: Sequence[int], step: 
 
 
 # ----------------------------------------------------------------------------- A2
-def predict_logits(arch, fold_state_dicts: List[dict], data, patch, step=0.5, mirror_axes=(0, 1)) -> torch.Tensor:
+def predict_logits(arch, fold_state_dicts: List[dict], data, patch, step=0.5, mirror_axes=(0, 1),
+                   tile_dtype: str = 'float') -> torch.Tensor:
     """``predict_logits_from_preprocessed_data``: per fold sliding-window prediction, summed, / n_folds."""
     data = _t(data).float()
     pred = None
     for sd in fold_state_dicts:
         net = lambda x, sd=sd: unet_forward(arch, sd, x)
-        p = predict_sliding_window(net, data, patch, step, mirror_axes)
+        p = predict_sliding_window(net, data, patch, step, mirror_axes, tile_dtype=tile_dtype)
         pred = p if pred is None else pred + p
     if len(fold_state_dicts) > 1:
         pred = pred / len(fold_state_dicts)

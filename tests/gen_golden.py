@@ -24,10 +24,25 @@ from totalsegmentator2d_amd.arch import UNetArch          # noqa: E402
 OUT = os.path.join(ROOT, 'tests', 'golden')
 
 
+def sliding_window_goldens():
+    """Sliding-window + mirroring + float16 aggregation end to end on a small net (A2-A5), in both blend orders:
+    ``logits_f16`` = fp32 tile (the reference's CPU path, the default), ``logits_f16_half`` = half tile (CUDA autocast)."""
+    for name, (arch, shape, patch, step, mirror, folds, seed) in cases.SW_CASES.items():
+        sds = [weights.synthetic_state_dict(arch, seed + f) for f in range(folds)]
+        data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
+        out = O.predict_logits(arch, sds, data, patch, step, mirror, tile_dtype='float').numpy()
+        out_h = O.predict_logits(arch, sds, data, patch, step, mirror, tile_dtype='half').numpy()
+        np.savez_compressed(os.path.join(OUT, f'{name}.npz'), logits_f16=out, logits_f16_half=out_h)
+        print(name, out.shape, out.dtype, 'elements differing between the two orders:', int((out != out_h).sum()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     import torch
     torch.set_num_threads(max(1, os.cpu_count() or 1))
+    if len(sys.argv) > 1 and sys.argv[1] == 'sw':       # only the sliding-window fixtures
+        sliding_window_goldens()
+        return
     # (i)+(ii) small architectures: full logits + every intermediate activation (per-kernel parity K1..K7)
     for name, (arch, B, H, W, seed) in cases.SMALL_CASES.items():
         sd = weights.synthetic_state_dict(arch, seed)
@@ -60,13 +75,7 @@ def main():
     g2 = O.compute_gaussian((64, 96)).numpy()
     np.savez_compressed(os.path.join(OUT, 'sliding_window.npz'), g512_diag=np.diag(g).copy(), g512_row0=g[0].copy(),
                         g512_centre=g[256].copy(), g64x96=g2, **{f'steps/{k}': v for k, v in steps.items()})
-    # sliding-window + mirroring + fp16 aggregation end to end on a small net (A2-A5)
-    for name, (arch, shape, patch, step, mirror, folds, seed) in cases.SW_CASES.items():
-        sds = [weights.synthetic_state_dict(arch, seed + f) for f in range(folds)]
-        data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
-        out = O.predict_logits(arch, sds, data, patch, step, mirror).numpy()
-        np.savez_compressed(os.path.join(OUT, f'{name}.npz'), logits_f16=out)
-        print(name, out.shape, out.dtype)
+    sliding_window_goldens()
     # (v) real-data plumbing: the reference's own sample assets (data files) + z-scored checksums
     adir = os.path.join(OUT, 'assets')
     os.makedirs(adir, exist_ok=True)

@@ -14,18 +14,19 @@ from totalsegmentator2d_amd.predictor import HIPnnUNetPredictor
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('order', ['float', 'half'])
 @pytest.mark.parametrize('name', list(cases.SW_CASES))
-def test_sliding_window_goldens(name):
+def test_sliding_window_goldens(name, order):
     arch, shape, patch, step, mirror, folds, seed = cases.SW_CASES[name]
     blobs = [blob_for(arch, seed + f)[1] for f in range(folds)]
     data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
-    p = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None)
+    p = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, tile_dtype=order)
     p.manual_initialization(arch, blobs, patch, inference_allowed_mirroring_axes=mirror)
     try:
         out = p.predict_logits_from_preprocessed_data(data).cpu().numpy()
     finally:
         p.close()
-    g = golden(name)['logits_f16']
+    g = golden(name)['logits_f16' if order == 'float' else 'logits_f16_half']
     assert out.dtype == np.float16 and out.shape == g.shape
     # reference end-of-pipeline logits are float16 (about 3 significant digits): allow 2 half-ulps at |x| <= 8
     assert np.abs(out.astype(np.float32) - g.astype(np.float32)).max() <= 1.6e-2
@@ -57,22 +58,23 @@ def test_config1_sample_s0616_canonical_net():
     assert (seg != seg_ref).mean() < 1e-3
 
 
+@pytest.mark.parametrize('order', ['float', 'half'])
 @pytest.mark.parametrize('name', list(cases.SW_CASES))
-def test_device_aggregation_is_bit_identical_to_host_aggregation(name):
+def test_device_aggregation_is_bit_identical_to_host_aggregation(name, order):
     """The device-side gather / mirror-average / fp16 Gaussian aggregation (ts2d_engine_predict_tiled) against the host
     numpy implementation fed with the SAME engine's per-tile logits: must agree bit for bit (same half arithmetic, same
     tile order)."""
     arch, shape, patch, step, mirror, folds, seed = cases.SW_CASES[name]
     blobs = [blob_for(arch, seed + f)[1] for f in range(folds)]
     data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
-    dev = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None)
+    dev = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, tile_dtype=order)
     dev.manual_initialization(arch, blobs, patch, inference_allowed_mirroring_axes=mirror)
     try:
         engines = dev.engines
 
         def net(batch, fold):
             return engines[fold].forward(np.ascontiguousarray(batch))[0]
-        host = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, network=net)
+        host = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, network=net, tile_dtype=order)
         host.manual_initialization(arch, blobs, patch, inference_allowed_mirroring_axes=mirror)
         a = dev.predict_logits_from_preprocessed_data(data).cpu().numpy()
         b = host.predict_logits_from_preprocessed_data(data).cpu().numpy()

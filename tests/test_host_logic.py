@@ -11,24 +11,25 @@ from totalsegmentator2d_amd import prng, weights
 from totalsegmentator2d_amd.predictor import HIPnnUNetPredictor
 
 
-def _predictor(arch, sds, patch, step, mirror):
+def _predictor(arch, sds, patch, step, mirror, order='float'):
     def net(batch, fold):   # row by row (B = 1) like upstream, so torch picks the same kernels as in the oracle run
         return np.concatenate([O.unet_forward(arch, sds[fold], batch[i:i + 1]).numpy() for i in range(batch.shape[0])])
-    p = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, network=net)
+    p = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, network=net, tile_dtype=order)
     p.manual_initialization(arch, [weights.pack_blob(arch, sd) for sd in sds], patch,
                             inference_allowed_mirroring_axes=mirror)
     return p
 
 
+@pytest.mark.parametrize('order', ['float', 'half'])
 @pytest.mark.parametrize('name', list(cases.SW_CASES))
-def test_predictor_host_logic_is_bit_faithful_to_upstream_aggregation(name):
+def test_predictor_host_logic_equals_the_aten_pinned_oracle_in_both_blend_orders(name, order):
     arch, shape, patch, step, mirror, folds, seed = cases.SW_CASES[name]
     sds = [blob_for(arch, seed + f)[0] for f in range(folds)]
     data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
-    p = _predictor(arch, sds, patch, step, mirror)
+    p = _predictor(arch, sds, patch, step, mirror, order)
     out = p.predict_logits_from_preprocessed_data(data)
     out = out.cpu().numpy() if hasattr(out, 'cpu') else out
-    ref = O.predict_logits(arch, sds, data, patch, step, mirror).numpy()
+    ref = O.predict_logits(arch, sds, data, patch, step, mirror, tile_dtype=order).numpy()
     assert out.dtype == np.float16 and out.shape == ref.shape == golden(name)['logits_f16'].shape
     # same per-tile network outputs (same torch kernels) => the numpy fp16 emulation must equal torch's half arithmetic
     assert np.array_equal(out, ref)
@@ -94,8 +95,9 @@ def test_randomised_window_configurations_match_the_torch_pipeline():
         arch = cases.unet(ns, feats, K, cin=cin)
         sds = [weights.synthetic_state_dict(arch, 700 + 10 * t + f) for f in range(folds)]
         data = prng.normal_f32(800 + t, 999, (cin,) + shape)
-        p = _predictor(arch, sds, patch, step, mirror)
+        order = ('float', 'half')[t % 2]
+        p = _predictor(arch, sds, patch, step, mirror, order)
         out = p.predict_logits_from_preprocessed_data(data)
         out = out.cpu().numpy() if hasattr(out, 'cpu') else out
-        ref = O.predict_logits(arch, sds, data, patch, step, mirror).numpy()
-        assert out.dtype == np.float16 and np.array_equal(out, ref), (t, feats, shape, patch, step, mirror, folds)
+        ref = O.predict_logits(arch, sds, data, patch, step, mirror, tile_dtype=order).numpy()
+        assert out.dtype == np.float16 and np.array_equal(out, ref), (t, feats, shape, patch, step, mirror, folds, order)

@@ -80,14 +80,51 @@ def test_zscore_of_reference_sample():
     assert props['bbox_used_for_cropping'] == [[0, 1], [0, 644], [0, 337]]
 
 
+def test_blend_order_is_pinned_by_plain_aten_statements():
+    """upstream's ``prediction *= gaussian; predicted_logits[sl] += prediction`` with float16
+    ``predicted_logits`` / ``gaussian``.  On the reference's CPU path the tile prediction is fp32 (``.to(results_device)`` moves
+    device, it does not cast), so ATen multiplies in fp32 and rounds ONCE into the half buffer; under CUDA autocast the tile
+    is half and product and sum each round.  The statements below are upstream's, on hand-made two-tile overlaps; the numpy
+    arithmetic of predictor.py / kernels_sw.h (restated here) must reproduce both orders bit for bit."""
+    import torch
+    rng = np.random.default_rng(5)
+    K, H, W, ph = 3, 48, 32, 32
+    g16 = O.compute_gaussian((ph, W))
+    tiles = [(0, torch.from_numpy(rng.normal(0, 3, (K, ph, W)).astype(np.float32))),
+             (16, torch.from_numpy(rng.normal(0, 3, (K, ph, W)).astype(np.float32)))]
+    outs = {}
+    for order in ('float', 'half'):
+        logits = torch.zeros((K, H, W), dtype=torch.half)
+        n_pred = torch.zeros((H, W), dtype=torch.half)
+        for y0, p32 in tiles:
+            prediction = p32.clone() if order == 'float' else p32.to(torch.half)
+            prediction *= g16
+            logits[:, y0:y0 + ph] += prediction
+            n_pred[y0:y0 + ph] += g16
+        logits /= n_pred
+        outs[order] = logits.numpy()
+        # the arithmetic the product uses (predictor.py host path == sw_aggregate)
+        acc = np.zeros((K, H, W), np.float16); n = np.zeros((H, W), np.float16); g = g16.numpy()
+        for y0, p32 in tiles:
+            p = p32.numpy()
+            if order == 'half':
+                acc[:, y0:y0 + ph] += p.astype(np.float16) * g
+            else:
+                acc[:, y0:y0 + ph] = (acc[:, y0:y0 + ph].astype(np.float32) + p * g.astype(np.float32)).astype(np.float16)
+            n[y0:y0 + ph] += g
+        assert np.array_equal(acc / n, outs[order]), order
+    assert (outs['float'] != outs['half']).any()          # the two orders are observably different
+
+
+@pytest.mark.parametrize('order', ['float', 'half'])
 @pytest.mark.parametrize('name', list(cases.SW_CASES))
-def test_torch_oracle_sliding_window_goldens(name):
+def test_torch_oracle_sliding_window_goldens(name, order):
     from tests.conftest import blob_for
     from totalsegmentator2d_amd import prng
     arch, shape, patch, step, mirror, folds, seed = cases.SW_CASES[name]
     sds = [blob_for(arch, seed + f)[0] for f in range(folds)]
     data = prng.normal_f32(seed, 999, (arch.input_channels,) + tuple(shape))
-    out = O.predict_logits(arch, sds, data, patch, step, mirror).numpy()
-    g = golden(name)['logits_f16']
+    out = O.predict_logits(arch, sds, data, patch, step, mirror, tile_dtype=order).numpy()
+    g = golden(name)['logits_f16' if order == 'float' else 'logits_f16_half']
     assert out.dtype == np.float16 and out.shape == g.shape
     assert np.abs(out.astype(np.float32) - g.astype(np.float32)).max() <= 8e-3   # <= a couple of fp16 ulps at |x| ~ 4

@@ -86,6 +86,7 @@ struct ts2d_engine {
     bool weights_ready = false;
     int precision = TS2D_PRECISION_F32_SPLIT_F16X3;
     int num_cus = 256;
+    int tile_half = 0;            // sliding-window blend order (ts2d_engine_set_tile_dtype): 0 = fp32 tile (reference CPU path)
     int tiled_inf = 0;            // the last predict_tiled produced an infinite aggregated logit (ts2d_engine_tiled_inf_flag)
     bool use_h32 = true;          // precision mode f16: 32-channel-chunk kernel (TS2D_H32=0 falls back to the 16-channel one)
     bool use_one = true;          // one-image-tile split kernel (TS2D_ONE=0 falls back to the generic one)
@@ -798,7 +799,7 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
 // ------------------------------------------------------------------------------------------------- C-ABI
 extern "C" {
 
-int ts2d_abi_version(void) { return 1; }
+int ts2d_abi_version(void) { return 2; }
 
 const char* ts2d_last_error(void) { return g_err.c_str(); }
 
@@ -853,6 +854,13 @@ int ts2d_engine_set_precision(ts2d_engine* e, int mode) {
     if (mode != TS2D_PRECISION_F32_EXACT && mode != TS2D_PRECISION_F32_SPLIT_F16X3 && mode != TS2D_PRECISION_F16)
         return fail(TS2D_ERR_INVALID, "unknown precision mode %d", mode);
     e->precision = mode;
+    return TS2D_OK;
+}
+
+int ts2d_engine_set_tile_dtype(ts2d_engine* e, int mode) {
+    if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_tile_dtype: null engine");
+    if (mode != TS2D_TILE_F32 && mode != TS2D_TILE_F16) return fail(TS2D_ERR_INVALID, "unknown tile dtype %d", mode);
+    e->tile_half = mode == TS2D_TILE_F16;
     return TS2D_OK;
 }
 
@@ -950,7 +958,7 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
         const long long total = (long long)K * Hp * Wp;
         hipLaunchKernelGGL(sw_aggregate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_log, K, Hp, Wp, ph, pw, n_tiles, V,
                            d_ty, d_tx, d_vf, gaussian_f16 ? d_g : nullptr, logits_f16 ? d_o16 : nullptr, seg_u8 ? d_seg : nullptr,
-                           kSigmoidHalfThreshold, total, d_flag);
+                           kSigmoidHalfThreshold, total, d_flag, e->tile_half);
         HIP_TRY(hipGetLastError());
     }
     e->tiled_inf = 0;

@@ -1,8 +1,12 @@
 // Device side of nnU-Net's sliding-window inference: tile gather with mirroring, and the
-// Gaussian-weighted aggregation in float16 exactly as upstream does it (predicted_logits / n_predictions / gaussian are
-// torch.half; every half operation = fp32 operation + round-to-nearest-even to half, which is what ATen's CPU half
-// kernels and numpy do).  Tiles are accumulated in upstream order per output pixel, so the result is bit-identical to the
-// host implementation in predictor.py (tests/test_gpu_predictor.py).
+// Gaussian-weighted aggregation into upstream's float16 buffers (predicted_logits / n_predictions / gaussian are torch.half;
+// a half operation = fp32 operation + round-to-nearest-even to half, which is what ATen's CPU half kernels and numpy do).
+// Two orders (ts2d_engine_set_tile_dtype; pinned by plain-ATen statements in tests/test_oracle.py):
+//   tile_half == 0 (default, the reference's CPU path): the mirror-averaged tile stays fp32, `p *= g` is fp32 x float(g) in
+//     fp32, `logits[sl] += p` is a float add with ONE cast to half;
+//   tile_half != 0 (the CUDA autocast path): the tile is cast to half first, the product and the sum each round to half.
+// Tiles are accumulated in upstream order per output pixel, so the result is bit-identical to the host implementation in
+// predictor.py (tests/test_gpu_predictor.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -32,7 +36,7 @@ __device__ __forceinline__ __half h_div(__half a, __half b) { return __float2hal
 __global__ void sw_aggregate(const float* __restrict__ logits, int K, int Hp, int Wp, int ph, int pw, int T, int V,
                              const int* __restrict__ tile_y, const int* __restrict__ tile_x, const int* __restrict__ vflip,
                              const __half* __restrict__ gauss, __half* __restrict__ out16, uint8_t* __restrict__ seg,
-                             float thr, long long total, int* __restrict__ inf_flag) {
+                             float thr, long long total, int* __restrict__ inf_flag, int tile_half) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int X = (int)(i % Wp); long long r = i / Wp;
@@ -50,9 +54,14 @@ __global__ void sw_aggregate(const float* __restrict__ logits, int K, int Hp, in
         }
         if (V > 1) y /= (float)V;
         const __half g = gauss ? gauss[(size_t)yy * pw + xx] : __float2half_rn(1.f);
-        __half p = __float2half_rn(y);
-        if (gauss) p = h_mul(p, g);
-        acc = h_add(acc, p);
+        if (tile_half) {
+            __half p = __float2half_rn(y);
+            if (gauss) p = h_mul(p, g);
+            acc = h_add(acc, p);
+        } else {      // (explicit _rn intrinsics: the product must round to fp32 before the add - no FMA contraction)
+            const float pf = gauss ? __fmul_rn(y, __half2float(g)) : y;
+            acc = __float2half_rn(__fadd_rn(__half2float(acc), pf));
+        }
         n = h_add(n, g);
     }
     const __half res = h_div(acc, n);

@@ -88,6 +88,12 @@ class Engine:
         m = {'exact': _lib.PRECISION_F32_EXACT, 'split': _lib.PRECISION_F32_SPLIT_F16X3, 'f16': _lib.PRECISION_F16}.get(mode, mode)
         _lib.check(self.lib.ts2d_engine_set_precision(self._h, int(m)), 'ts2d_engine_set_precision')
 
+    def set_tile_dtype(self, mode):
+        """Blend order of :meth:`predict_tiled`: 'float' (reference CPU path: fp32 tile, one rounding into the half buffer;
+        the default) or 'half' (CUDA autocast path: half tile, half product, half sum)."""
+        m = {'float': 0, 'half': 1}.get(mode, mode)
+        _lib.check(self.lib.ts2d_engine_set_tile_dtype(self._h, int(m)), 'ts2d_engine_set_tile_dtype')
+
     # ------------------------------------------------------------------ forward
     def reserve(self, B: int, H: int, W: int):
         _lib.check(self.lib.ts2d_engine_reserve(self._h, B, H, W), 'ts2d_engine_reserve')

@@ -51,8 +51,11 @@ class HIPnnUNetPredictor:
     def __init__(self, tile_step_size: float = 0.5, use_gaussian: bool = True, use_mirroring: bool = True,
                  perform_everything_on_device: bool = True, device=None, verbose: bool = False,
                  verbose_preprocessing: bool = False, allow_tqdm: bool = True, max_batch: int = 64, precision: str = 'split',
-                 network: Optional[Callable[[np.ndarray], np.ndarray]] = None):
-        """``network``: test hook - a callable [B,C,h,w] -> [B,K,h,w] used INSTEAD of creating HIP engines (host-logic
+                 tile_dtype: str = 'float', network: Optional[Callable[[np.ndarray], np.ndarray]] = None):
+        """``tile_dtype``: dtype of a tile prediction when it is blended into upstream's float16 buffers - 'float' (default;
+        the reference's CPU path: fp32 tile x half gaussian in fp32, ONE rounding per ``logits[sl] += p``) or 'half' (the CUDA
+        autocast path: the tile is half, the product and the sum each round to half).
+        ``network``: test hook - a callable [B,C,h,w] -> [B,K,h,w] used INSTEAD of creating HIP engines (host-logic
         unit tests on machines without a GPU).  The product path never passes it."""
         self.tile_step_size = tile_step_size
         self.use_gaussian = use_gaussian
@@ -65,6 +68,9 @@ class HIPnnUNetPredictor:
         if precision not in ('split', 'exact', 'f16'):
             raise ValueError("precision must be 'split' (fp32-equivalent, default), 'exact' (fp32 MFMA) or 'f16' (like the reference's CUDA autocast path)")
         self.precision = precision
+        if tile_dtype not in ('float', 'half'):
+            raise ValueError("tile_dtype must be 'float' (reference CPU path, default) or 'half' (CUDA autocast path)")
+        self.tile_dtype = tile_dtype
         idx = 0
         if device is not None:
             idx = getattr(device, 'index', device)
@@ -144,6 +150,7 @@ class HIPnnUNetPredictor:
         self.engines = [Engine(self.arch, blob, self.device.index) for blob in self.list_of_parameters]
         for e in self.engines:
             e.set_precision(self.precision)
+            e.set_tile_dtype(self.tile_dtype)
 
     def close(self):
         for e in self.engines:
@@ -210,10 +217,16 @@ class HIPnnUNetPredictor:
                 p += np.flip(y[t * nv + v], [a - 1 for a in combos[v]])
             if nv > 1:
                 p /= np.float32(nv)
-            p = p.astype(np.float16)
-            if self.use_gaussian:
-                p = p * g
-            logits[:, d, sx:sx + patch[0], sy:sy + patch[1]] += p
+            sl = (slice(None), d, slice(sx, sx + patch[0]), slice(sy, sy + patch[1]))
+            if self.tile_dtype == 'half':          # CUDA autocast order: half tile, half product, half sum (three roundings)
+                p = p.astype(np.float16)
+                if self.use_gaussian:
+                    p = p * g
+                logits[sl] += p
+            else:                                  # reference CPU path: fp32 tile * float(g) in fp32, ONE rounding into the half buffer
+                if self.use_gaussian:
+                    p = p * g.astype(np.float32)
+                logits[sl] = (logits[sl].astype(np.float32) + p).astype(np.float16)
             n_pred[d, sx:sx + patch[0], sy:sy + patch[1]] += g
         logits = logits / n_pred
         if _any_inf_f16(logits):
