@@ -108,3 +108,26 @@ def test_infinite_aggregated_logit_is_detected_on_the_device():
         assert p.engines[0].last_tiled_inf is True
     finally:
         p.close()
+
+
+def test_runs_on_different_streams_share_the_workspace_in_order():
+    """One handle, one activation workspace: an asynchronous torch-tensor forward (side stream) followed IMMEDIATELY by a
+    sliding-window call (the engine's own stream) of a shape that fits the reserved workspace must not overwrite the first
+    run's activations - the engine orders the runs with an end-of-run event (no host synchronisation in between)."""
+    import torch
+    from totalsegmentator2d_amd.engine import Engine
+    arch = cases.unet(4, (32, 64, 128, 256), 5)
+    _, blob = blob_for(arch, 41)
+    x = torch.from_numpy(prng.normal_f32(41, 1000, (40, 2, 128, 128))).cuda()
+    img = prng.normal_f32(42, 999, (2, 128, 128))
+    with Engine(arch, blob) as e:
+        ref, _ = e.forward(x)
+        torch.cuda.synchronize()
+        ref = ref.clone()
+        t16, _ = e.predict_tiled(img, (128, 128), [(0, 0)], (0, 1), None)
+        for _ in range(4):
+            lg, _ = e.forward(x)                                              # asynchronous, torch side stream
+            o16, _ = e.predict_tiled(img, (128, 128), [(0, 0)], (0, 1), None)   # engine stream, same workspace, no sync
+            torch.cuda.synchronize()
+            assert torch.equal(lg, ref)
+            assert np.array_equal(o16, t16)

@@ -38,3 +38,29 @@ def test_write_read_roundtrip(tmp_path):
     nrrd.write(v, str(tmp_path / 'v.nrrd'))
     b = nrrd.read(str(tmp_path / 'v.nrrd'))
     assert np.array_equal(b.array, vol) and b.spacing == (1.0, 2.0, 3.0) and b.space == 'left-posterior-superior'
+
+
+def test_ras_space_is_read_as_lps(tmp_path):
+    """ITK's NrrdImageIO presents every anatomical NRRD space as LPS (R and A world axes negated in directions and origin).  The
+    same volume stored in RAS and in LPS must reorient and project identically - otherwise left/right labels come out swapped."""
+    from totalsegmentator2d_amd import image
+    rng = np.random.default_rng(1)
+    vol = rng.integers(-1000, 2000, size=(9, 7, 5)).astype(np.int16)
+    lps = nrrd.Image(vol, (1.5, 2.0, 2.5), (10.0, -20.0, 30.0), (-1, 0, 0, 0, -1, 0, 0, 0, 1), space='left-posterior-superior')
+    nrrd.write(lps, str(tmp_path / 'lps.nrrd'))
+    # the same geometry expressed in RAS: world x and y negated
+    head, payload = open(tmp_path / 'lps.nrrd', 'rb').read().split(b'\n\n', 1)
+    txt = head.decode('latin1').replace('space: left-posterior-superior', 'space: right-anterior-superior')
+    txt = txt.replace('space directions: (-1.5,0,0) (0,-2,0) (0,0,2.5)', 'space directions: (1.5,0,0) (0,2,0) (0,0,2.5)')
+    txt = txt.replace('space origin: (10,-20,30)', 'space origin: (-10,20,30)')
+    assert 'right-anterior-superior' in txt and '(1.5,0,0)' in txt and '(-10,20,30)' in txt
+    open(tmp_path / 'ras.nrrd', 'wb').write(txt.encode('latin1') + b'\n\n' + payload)
+    a, b = nrrd.read(str(tmp_path / 'lps.nrrd')), nrrd.read(str(tmp_path / 'ras.nrrd'))
+    assert b.space == 'left-posterior-superior' and a.direction == b.direction and a.origin == b.origin
+    ra, rb = image.reorient_image(a, 'RAI'), image.reorient_image(b, 'RAI')
+    assert np.array_equal(ra.array, rb.array)
+    assert np.array_equal(image.project(ra, 'max', 'coronal').array, image.project(rb, 'max', 'coronal').array)
+    las = txt.replace('right-anterior-superior', 'left-anterior-superior').replace('(1.5,0,0)', '(-1.5,0,0)').replace('(-10,20,30)', '(10,20,30)')
+    open(tmp_path / 'las.nrrd', 'wb').write(las.encode('latin1') + b'\n\n' + payload)
+    c = nrrd.read(str(tmp_path / 'las.nrrd'))
+    assert c.direction == a.direction and c.origin == a.origin

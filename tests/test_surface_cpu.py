@@ -110,3 +110,43 @@ def test_cli_file_names(tmp_path, two_models):
     out = sorted(os.listdir(tmp_path / 'out'))
     assert out == ['sample_s0521-cardiac.seg.nrrd', 'sample_s0521-ribs.seg.nrrd', 'sample_s0521.seg.nrrd',
                    'sample_s0521_max.nrrd', 'sample_s0521_mean.nrrd']
+
+
+def test_label_colours_are_stamped_like_the_reference(tmp_path):
+    """reference ts2d/tool.py:29-33 passes the packaged label-colors.csv as 'nnu.result.colors'; meta.py:219-231 stamps
+    Segment*_Color as three 0..1 floats with three decimals."""
+    from totalsegmentator2d_amd.zoo import get_label_colors
+    colors = get_label_colors()
+    assert len(colors) >= 117 and colors['autochthon-left'] == '#9370DB'
+    assert image.to_color_str_rgb_floats('#9370DB') == '0.576 0.439 0.859'
+    assert image.to_color_str_rgb_floats((255, 0, 128)) == '1.000 0.000 0.502'
+    seg = nrrd.Image(np.zeros((4, 4, 2), np.uint8), (1.0, 1.0), (0.0, 0.0), (1.0, 0.0, 0.0, 1.0), components=2)
+    image.set_annotation_meta(seg, {1: 'autochthon-left', 2: 'no-such-label'}, colors)
+    assert seg.meta['Segment0_Color'] == '0.576 0.439 0.859' and seg.meta['Segment0_ColorAutoGenerated'] == '0'
+    assert 'Segment1_Color' not in seg.meta and seg.meta['Segment1_Name'] == 'no-such-label'
+
+
+def test_stage_named_errors(two_models):
+    """reference prediction_worker.py:183-242: '<Stage> failed for <name>: <cause>', wrapped by nnu.py:217-219."""
+    m = two_models['ts2d-v2-ep4000b2_cardiac']
+    m.start()
+    try:
+        bad = nrrd.Image(np.zeros((8, 8, 3), np.float32), (1.5, 1.5), (0.0, 0.0), (1.0, 0.0, 0.0, 1.0), components=3)
+        with pytest.raises(RuntimeError, match=r'Prediction failed for: image1: (Preprocessing|Prediction) failed for image1'):
+            m.apply(bad)
+    finally:
+        m.stop()
+
+
+def test_case_enumeration(tmp_path):
+    for fn in ('a.nrrd', 'b.seg.nrrd', 'c.nii.gz', 'd.txt', 'noext'):
+        (tmp_path / fn).write_bytes(b'x')
+    assert [n for n, _ in _enumerate_cases(str(tmp_path))] == ['a']            # 'b.seg.nrrd' has extension 'seg.nrrd'
+    with pytest.raises(ValueError, match='Unsupported file extension'):
+        _enumerate_cases(str(tmp_path / 'd.txt'))
+    with pytest.raises(ValueError, match='only NRRD'):
+        _enumerate_cases(str(tmp_path / 'c.nii.gz'))
+    with pytest.raises(FileNotFoundError):
+        _enumerate_cases(str(tmp_path / 'missing.nrrd'))
+    with pytest.raises(ValueError, match='does not have an extension'):
+        _enumerate_cases(str(tmp_path / 'noext'))

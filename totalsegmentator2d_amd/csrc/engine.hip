@@ -12,6 +12,7 @@
 #include "kernels_sw.h"
 #include "kernels_project.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -69,6 +70,19 @@ struct Op {
 
 struct Launch { std::string name; hipEvent_t e0 = nullptr, e1 = nullptr; };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one process may drive engines on several GPUs
+// (include/ts2d_engine.h: handles are independent), so the "already set" state is a bit per device, not one flag per process.
+inline hipError_t allow_max_lds(const void* kern, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -100,6 +114,9 @@ struct ts2d_engine {
     std::vector<Launch> launches; size_t n_launched = 0;
     int lastB = 0, lastH = 0, lastW = 0; hipStream_t last_stream = nullptr; bool last_f16 = false;
     char* d_sw = nullptr; size_t sw_bytes = 0;     // sliding-window scratch (image, batch, tile logits, outputs)
+    // The activation workspace is shared by every call on this handle, whatever stream the caller passes: the end of each run
+    // is marked with an event, and a run issued on ANOTHER stream first waits for it (no host synchronisation).
+    hipEvent_t ws_event = nullptr; hipStream_t ws_stream = nullptr; bool ws_busy = false;
 };
 
 namespace {
@@ -387,13 +404,9 @@ TileGeom tile_geom(int B, int Ht, int Wt, int stride, int taps) {
 
 template <int TAPS, int STRIDE, int CK, int BN, int EPI>
 hipError_t launch_conv_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_done{0};
     auto kern = conv_mfma_f32<TAPS, STRIDE, CK, BN, EPI>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(kern), attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
@@ -412,13 +425,9 @@ hipError_t launch_conv(int taps, int stride, int ck, int bn, const ConvArgs& a, 
 
 template <int BN, int MAXU, typename ST, int NP>
 hipError_t launch_split_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_done{0};
     auto kern = conv3x3_f16x3<BN, MAXU, 1, ST, NP>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(kern), attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
@@ -437,25 +446,17 @@ hipError_t launch_split(bool f16, int bn, int maxu, const ConvArgs& a, int grid,
 
 template <int BN, bool PFS>
 hipError_t launch_one_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_done{0};
     auto kern = conv3x3_f16x3_one<BN, PFS>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(kern), attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
 template <int BN, bool PFS, bool PIPE, typename ST, int NP>
 hipError_t launch_one_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_done{0};
     auto kern = conv3x3s2_f16x3_one<BN, PFS, PIPE, ST, NP>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(kern), attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
@@ -473,13 +474,9 @@ hipError_t launch_one(int bn, const ConvArgs& a, int grid, size_t smem, hipStrea
 
 template <int BN, int MAXU>
 hipError_t launch_h32_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_done{0};
     auto kern = conv3x3_h32<BN, MAXU>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(kern), attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
@@ -491,13 +488,9 @@ hipError_t launch_h32(int bn, const ConvArgs& a, int grid, size_t smem, hipStrea
 
 template <int BN, int MAXU, typename ST, int NP>
 hipError_t launch_split_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_done{0};
     auto kern = conv3x3s2_f16x3<BN, MAXU, ST, NP>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(kern), attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
@@ -556,7 +549,10 @@ size_t part_floats_needed(const ts2d_engine* e, int B, int H, int W) {
 int ensure_workspace(ts2d_engine* e, int B, int H, int W) {
     if (e->d_ws && e->wsB >= B && e->wsH == H && e->wsW == W) return TS2D_OK;
     HIP_TRY(hipSetDevice(e->device));
-    if (e->d_ws) { HIP_TRY(hipStreamSynchronize(e->stream)); HIP_TRY(hipFree(e->d_ws)); e->d_ws = nullptr; e->ws_bytes = 0; }
+    if (e->d_ws) {      // the old workspace may still be in use by a run on ANY stream: wait for its end-of-run event
+        if (e->ws_busy) { HIP_TRY(hipEventSynchronize(e->ws_event)); e->ws_busy = false; }
+        HIP_TRY(hipStreamSynchronize(e->stream)); HIP_TRY(hipFree(e->d_ws)); e->d_ws = nullptr; e->ws_bytes = 0;
+    }
     const int K = e->arch.num_classes;
     size_t off = 0;
     std::vector<size_t> o_data(e->tensors.size()), o_sc(e->tensors.size()), o_sh(e->tensors.size());
@@ -610,7 +606,27 @@ int prof_end(ts2d_engine* e, hipStream_t st) {
 
 #define TRY(expr) do { int _rc = (expr); if (_rc != TS2D_OK) return _rc; } while (0)
 
+int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st);
+
+// Order this run after the previous user of the workspace if that one ran on a different stream.
+int workspace_acquire(ts2d_engine* e, hipStream_t st) {
+    if (e->ws_busy && e->ws_stream != st) HIP_TRY(hipStreamWaitEvent(st, e->ws_event, 0));
+    return TS2D_OK;
+}
+int workspace_release(ts2d_engine* e, hipStream_t st) {
+    HIP_TRY(hipEventRecord(e->ws_event, st));
+    e->ws_stream = st; e->ws_busy = true;
+    return TS2D_OK;
+}
+
 int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st) {
+    TRY(workspace_acquire(e, st));
+    const int rc = run_forward_impl(e, d_in, B, H, W, d_logits, d_mask, st);
+    const int rc2 = workspace_release(e, st);       // also after a failed launch: earlier kernels of the run may be in flight
+    return rc != TS2D_OK ? rc : rc2;
+}
+
+int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st) {
     const ts2d_arch_desc& a = e->arch;
     e->n_launched = 0;
     e->lastB = B; e->lastH = H; e->lastW = W; e->last_stream = st;
@@ -775,15 +791,15 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
                 if (f16) hipLaunchKernelGGL((head_mfma32<_Float16, 1>), dim3(gridm), dim3(256), 0, st, ha, bpw);
                 else hipLaunchKernelGGL((head_mfma32<float, 3>), dim3(gridm), dim3(256), 0, st, ha, bpw);
             } else if (src.C == 32) {
-                static bool set32 = false;
-                if (!set32) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<32, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<32, _Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set32 = true; }
+                static std::atomic<uint64_t> set32a{0}, set32b{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(head_1x1<32, float>), set32a));
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(head_1x1<32, _Float16>), set32b));
                 if (f16) hipLaunchKernelGGL((head_1x1<32, _Float16>), dim3(grid), dim3(256), smem, st, ha);
                 else hipLaunchKernelGGL((head_1x1<32, float>), dim3(grid), dim3(256), smem, st, ha);
             } else {
-                static bool set64 = false;
-                if (!set64) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<64, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(head_1x1<64, _Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set64 = true; }
+                static std::atomic<uint64_t> set64a{0}, set64b{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(head_1x1<64, float>), set64a));
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(head_1x1<64, _Float16>), set64b));
                 if (f16) hipLaunchKernelGGL((head_1x1<64, _Float16>), dim3(grid), dim3(256), smem, st, ha);
                 else hipLaunchKernelGGL((head_1x1<64, float>), dim3(grid), dim3(256), smem, st, ha);
             }
@@ -822,6 +838,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
     if (rc != TS2D_OK) { delete e; return rc; }
     hipError_t he = hipSetDevice(device);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ws_event, hipEventDisableTiming);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&e->d_weights), e->weight_floats * sizeof(float));
     if (he != hipSuccess) {
         rc = fail(he == hipErrorOutOfMemory ? TS2D_ERR_NOMEM : TS2D_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he));
@@ -839,6 +856,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
 int ts2d_engine_load_weights(ts2d_engine* e, const float* weights, size_t n_floats) {
     if (!e || !weights) return fail(TS2D_ERR_INVALID, "ts2d_engine_load_weights: null argument");
     HIP_TRY(hipSetDevice(e->device));
+    if (e->ws_busy) { HIP_TRY(hipEventSynchronize(e->ws_event)); e->ws_busy = false; }     // a run on any stream may still read the old weights
     HIP_TRY(hipStreamSynchronize(e->stream));
     return upload_weights(e, weights, n_floats);
 }
@@ -1069,7 +1087,9 @@ size_t ts2d_engine_device_bytes(ts2d_engine* e) { return e ? e->weight_floats * 
 int ts2d_engine_destroy(ts2d_engine* e) {
     if (!e) return TS2D_OK;
     (void)hipSetDevice(e->device);
+    if (e->ws_busy) (void)hipEventSynchronize(e->ws_event);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->ws_event) (void)hipEventDestroy(e->ws_event);
     for (Launch& l : e->launches) { if (l.e0) (void)hipEventDestroy(l.e0); if (l.e1) (void)hipEventDestroy(l.e1); }
     if (e->d_ws) (void)hipFree(e->d_ws);
     if (e->d_sw) (void)hipFree(e->d_sw);

@@ -182,10 +182,22 @@ def restore_dimension(seg: Image, ref: Image) -> Image:
 
 # ----------------------------------------------------------------------------- segmentation metadata (3D-Slicer keys)
 def to_color_str_rgb_floats(color, sep: str = ' ') -> str:
-    c = [float(v) for v in color]
-    if max(c) > 1.0:
-        c = [v / 255.0 for v in c]
-    return sep.join(repr(round(v, 6)) for v in c[:3])
+    """Colour -> 'r g b' floats in [0,1] with three decimals, as the reference stamps ``Segment*_Color`` (``ts2d/core/util/
+    color.py:81-85`` -> ``format_array(p=3)``): accepts '#RRGGBB' strings (the packaged label-colors.csv), integer 0..255
+    triples and float 0..1 triples."""
+    if isinstance(color, str):
+        h = color.strip().lstrip('#')
+        if len(h) != 6:
+            raise ValueError(f"unsupported colour string: {color!r}")
+        c = [int(h[i:i + 2], 16) for i in (0, 2, 4)]
+    else:
+        c = list(color)[:3]
+        if len(c) != 3:
+            raise ValueError(f"colour tuples need three components, found {color!r}")
+        if any(not isinstance(v, (int, np.integer)) for v in c):
+            c = [int(min(max(float(v), 0.0), 1.0) * 255) for v in c]          # reference tuple_to_color: floats are 0..1
+        c = [min(max(int(v), 0), 255) for v in c]
+    return sep.join(np.format_float_positional(v / 255.0, precision=3, unique=False) for v in c)
 
 
 def set_annotation_meta(seg: Image, names: Optional[Dict[int, str]] = None, colors: Optional[Dict[str, Sequence[float]]] = None):

@@ -8,28 +8,38 @@ from .tool import TS2D
 from .zoo import DEFAULT_MODEL
 
 
+_KNOWN_EXT = ('nrrd', 'nii', 'nii.gz', 'mha', 'mhd')     # what the reference CLI accepts (ts2d/main.py:25)
+_READABLE_EXT = ('nrrd',)                                 # what this build can read (no SimpleITK / nibabel)
+
+
+def _check_case(path: str):
+    """(case name, path) for one input file, or a ValueError / FileNotFoundError saying why it is not a case."""
+    if not os.path.isfile(path):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"Source file does not exist: {path}")
+        raise ValueError(f"Source is not a regular file: {path}")
+    name, dot, ext = os.path.basename(path).partition('.')           # case name = up to the FIRST dot ('a.nii.gz' -> 'a')
+    if not dot:
+        raise ValueError(f"Source file does not have an extension: {os.path.basename(path)}")
+    if ext not in _KNOWN_EXT:
+        raise ValueError(f"Unsupported file extension: {ext} in {os.path.basename(path)}")
+    if ext not in _READABLE_EXT:
+        raise ValueError(f"only NRRD input is implemented in the MI355X build (no SimpleITK): {os.path.basename(path)}")
+    return name, path
+
+
 def _enumerate_cases(src: str):
-    isdir = os.path.isdir(src)
-    files = glob(os.path.join(src, "*.*")) if isdir else [src]
-    for fp in sorted(files):
+    """A single file must be a valid case (its error propagates); a directory contributes every file that is one and silently
+    skips the rest - the behaviour of the reference CLI (ts2d/main.py:10-32), in sorted order."""
+    if not os.path.isdir(src):
+        return [_check_case(src)]
+    cases = []
+    for path in sorted(glob(os.path.join(src, "*.*"))):
         try:
-            if not os.path.exists(fp):
-                raise FileNotFoundError(f"Source file does not exist: {fp}")
-            if not os.path.isfile(fp):
-                raise ValueError(f"Source is not a regular file: {fp}")
-            fn = os.path.basename(fp)
-            if '.' not in fn:
-                raise ValueError(f"Source file does not have an extension: {fn}")
-            name, ext = fn.split(".", maxsplit=1)
-            if ext not in ('nrrd', 'nii', 'nii.gz', 'mha', 'mhd'):
-                raise ValueError(f"Unsupported file extension: {ext} in {fn}")
-            if ext != 'nrrd':
-                raise ValueError(f"only NRRD input is implemented in the MI355X build (no SimpleITK): {fn}")
-            yield name, fp
-        except Exception:
-            if isdir:
-                continue
-            raise
+            cases.append(_check_case(path))
+        except (ValueError, FileNotFoundError):
+            pass
+    return cases
 
 
 def ts2d_run(src: str, dest: str, model: str = None, use_remote: bool = True, fetch_remote: bool = True, collapse: bool = False,

@@ -133,24 +133,39 @@ class HIPModel:
         return next(iter(results.values())) if single else results
 
     def _apply_one(self, name, img, result_dir, override):
+        """The reference worker's four stages (``prediction_worker.py:177-242``), each failing under its own name -
+        ``"<Stage> failed for <name>: <cause>"`` - so that a HIP error (``ts2d_last_error``) tells which stage raised it."""
         p = self._predictor
         ts = self.timestamps = {'start': time.time()}
-        ref = nrrd.read(img) if isinstance(img, str) else img
-        from .preprocess import image_to_array
-        data, props = image_to_array(ref)
-        pre = p.configuration_manager.preprocessor_class(verbose=p.verbose)
-        data, _, props = pre.run_case_npy(data, None, props, p.plans_manager, p.configuration_manager, p.dataset_json)
-        ts['preprocessed'] = time.time()
-        logits = p.predict_logits_from_preprocessed_data(data)
-        logits = logits.cpu().numpy() if hasattr(logits, 'cpu') else logits
-        ts['predicted'] = time.time()
         ofile = None
-        if result_dir is not None:
-            os.makedirs(result_dir, exist_ok=True)
-            ofile = os.path.join(result_dir, name)
-            if not override and os.path.exists(ofile + '.nrrd'):
-                return ofile + '.nrrd'
-        seg = export_prediction_from_logits(logits, props, p.configuration_manager, p.plans_manager, p.dataset_json, ofile,
-                                            ref_image=ref, labels=self.labels, colors=self.colors if isinstance(self.colors, dict) else None)
-        ts['exported'] = ts['done'] = time.time()
+        try:
+            if result_dir is not None:
+                os.makedirs(result_dir, exist_ok=True)
+                ofile = os.path.join(result_dir, name)
+                if not override and os.path.exists(ofile + '.nrrd'):
+                    return ofile + '.nrrd'
+        except Exception as ex:
+            raise RuntimeError(f"Could not create output directory: {ex}") from ex
+        try:
+            ref = nrrd.read(img) if isinstance(img, str) else img
+            from .preprocess import image_to_array
+            data, props = image_to_array(ref)
+            pre = p.configuration_manager.preprocessor_class(verbose=p.verbose)
+            data, _, props = pre.run_case_npy(data, None, props, p.plans_manager, p.configuration_manager, p.dataset_json)
+            ts['preprocessed'] = time.time()
+        except Exception as ex:
+            raise RuntimeError(f"Preprocessing failed for {name}: {ex}") from ex
+        try:
+            logits = p.predict_logits_from_preprocessed_data(data)
+            logits = logits.cpu().numpy() if hasattr(logits, 'cpu') else logits
+            ts['predicted'] = time.time()
+        except Exception as ex:
+            raise RuntimeError(f"Prediction failed for {name}: {ex}") from ex
+        try:
+            seg = export_prediction_from_logits(logits, props, p.configuration_manager, p.plans_manager, p.dataset_json, ofile,
+                                                ref_image=ref, labels=self.labels,
+                                                colors=self.colors if isinstance(self.colors, dict) else None)
+            ts['exported'] = ts['done'] = time.time()
+        except Exception as ex:
+            raise RuntimeError(f"Export failed for {name}: {ex}") from ex
         return (ofile + '.nrrd') if result_dir is not None else seg

@@ -131,7 +131,28 @@ def read(path: str) -> Image:
         spacing = tuple(float(s) for s in sp.split()[-dim:]) if sp else (1.0,) * dim
         direction = tuple(1.0 if i == j else 0.0 for i in range(dim) for j in range(dim))
     origin = tuple(_parse_vec(fields['space origin'])) if 'space origin' in fields else (0.0,) * dim
-    return Image(arr, spacing, origin, direction, components, meta, fields.get('space'))
+    space = fields.get('space')
+    flips = _LPS_FLIPS.get(space.strip().lower()) if space else None
+    if flips:
+        # ITK's NrrdImageIO hands every anatomical space to the application as LPS: the world axes named R (vs L) and A (vs P)
+        # are negated in the direction vectors and the origin.  Everything downstream (reorient_image, projection axis) reads
+        # the direction matrix as LPS, so a RAS file must not be taken literally (it would come out mirrored in L/R and A/P).
+        sd = len(origin)
+        d = np.asarray(direction, dtype=np.float64).reshape(sd, -1)
+        for ax in flips:
+            if ax < sd:
+                d[ax] = -d[ax]
+        direction = tuple(float(v) + 0.0 for v in d.reshape(-1))            # (+ 0.0: no negative zeros)
+        origin = tuple((-o if i in flips else o) + 0.0 for i, o in enumerate(origin))
+        space = 'left-posterior-superior' + ('-time' if space.strip().lower().endswith('time') or space.strip().upper().endswith('T') else '')
+    return Image(arr, spacing, origin, direction, components, meta, space)
+
+
+# world axes to negate so that a named anatomical NRRD space becomes LPS (what ITK's reader does; other spaces pass through)
+_LPS_FLIPS = {
+    'right-anterior-superior': (0, 1), 'ras': (0, 1), 'right-anterior-superior-time': (0, 1), 'rast': (0, 1),
+    'left-anterior-superior': (1,), 'las': (1,), 'left-anterior-superior-time': (1,), 'last': (1,),
+}
 
 
 def _fmt(v: float) -> str:

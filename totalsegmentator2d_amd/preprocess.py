@@ -95,7 +95,12 @@ class DefaultPreprocessor:
             target_spacing = [original_spacing[0]] + target_spacing
         new_shape = [int(round(i / j * k)) for i, j, k in zip(original_spacing, target_spacing, data.shape[1:])]
         schemes = getattr(configuration_manager, 'normalization_schemes', None) or ['ZScoreNormalization'] * data.shape[0]
+        use_mask = getattr(configuration_manager, 'use_mask_for_norm', None) or [False] * data.shape[0]
         for c in range(data.shape[0]):
+            if schemes[c] == 'ZScoreNormalization' and c < len(use_mask) and use_mask[c]:
+                # upstream then takes mean/std inside the nonzero mask only and leaves the outside at 0 - refuse rather than
+                # normalise differently in silence
+                raise NotImplementedError(f"use_mask_for_norm is set for channel {c}: masked ZScoreNormalization is not implemented")
             if schemes[c] not in ('ZScoreNormalization', 'NoNormalization'):
                 raise NotImplementedError(f"normalization scheme {schemes[c]} is not implemented")
             if schemes[c] == 'ZScoreNormalization':

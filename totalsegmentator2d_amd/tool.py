@@ -18,7 +18,7 @@ from . import nrrd
 from .image import (cast, combine_segmentations, compose, get_actual_dimension, project, reduce_dimensions, reorient_image,
                     restore_dimension, split_channels)
 from .model import HIPModel
-from .zoo import LocalZoo, decompose_model_key
+from .zoo import LocalZoo, decompose_model_key, get_label_colors
 
 
 def _as_list(v):
@@ -39,13 +39,15 @@ class TS2D:
             models = {}
             for mid in ids:
                 try:
-                    cfg = self.zoo.load_config(mid, {'server.workers': 1})
+                    cfg = self.zoo.load_config(mid, {'server.workers': 1, 'nnu.result.colors': get_label_colors()})
                     cfg['device'] = device
                     models[mid] = HIPModel(cfg)
                 except Exception as ex:
                     raise RuntimeError(f"Failed to load model {mid}" + (f" (resolved from {key})" if key != mid else "")) from ex
         for mid, model in models.items():
             try:
+                if getattr(model, 'colors', None) is None:      # reference tool.py:29-33: every model gets the packaged label colours
+                    model.colors = get_label_colors()
                 model.start(wait=False)
                 if not model.multilabel:
                     warnings.warn(f"The loaded model {mid} is not configured for multilabel inference.")

@@ -16,6 +16,22 @@ DEFAULT_MODEL = 'ts2d-v2-ep4000b2'
 DEFAULT_RESOLVE = {'ts2d': 'ts2d-v2', 'ts2d-v2': 'ts2d-v2-ep4000b2', 'ts2d-v1': 'ts2d-v1-ep4000b2'}
 
 
+_LABEL_COLORS = None
+
+
+def get_label_colors() -> Dict[str, str]:
+    """label name (lower case) -> '#RRGGBB' from the packaged ``data/label-colors.csv`` (the reference's own data file, read
+    by ``ts2d/core/util/config.py:13-20`` and passed to every model as ``nnu.result.colors``, ``ts2d/tool.py:29-33``)."""
+    global _LABEL_COLORS
+    if _LABEL_COLORS is None:
+        import csv
+        fp = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'label-colors.csv')
+        with open(fp, newline='') as f:
+            _LABEL_COLORS = {row['Label'].strip().lower(): row['Color'].strip() for row in csv.DictReader(f)
+                             if row.get('Label') and row.get('Color')}
+    return _LABEL_COLORS
+
+
 def models_root() -> str:
     return os.environ.get('TS2D_MODELS', os.path.join(os.path.expanduser('~'), '.ts2d', 'models'))
 
