@@ -219,6 +219,10 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
     _, blob = blob_for(arch, seed)
     x = cases.make_input(arch, B, H, W, seed)
     names = ['enc0.c0', 'enc0.c1', 'enc1.c0', 'enc2.c1', 'enc4.c1', 'dec3.c0', 'dec1.c1', 'dec0.c0', 'dec0.c1']
+    with Engine(arch, blob) as e:                          # default path: includes the resident-weight 32 -> 32 kernel
+        lgr, _ = e.forward(x, logits=True)
+        tr = {n: e.debug_tensor(n) for n in names}
+    monkeypatch.setenv('TS2D_RES', '0')                    # (conv3x3_res32 sums in another order: compared by value below)
     with Engine(arch, blob) as e:
         lg1, _ = e.forward(x, logits=True)
         t1 = {n: e.debug_tensor(n) for n in names}
@@ -229,6 +233,10 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
     for n in names:
         assert np.array_equal(t0[n], t1[n]), n
     assert np.abs(lg0 - lg1).max() <= 1e-5
+    # conv3x3_res32 (one 288-term accumulation per output instead of two 144-term chunks): same values to fp32 rounding
+    for n in names:
+        assert np.abs(tr[n] - t1[n]).max() <= 2e-5, n
+    assert np.abs(lgr - lg1).max() <= 2e-5
 
 
 def test_randomised_shapes_against_the_torch_oracle():

@@ -9,6 +9,7 @@
 #include "kernels_head.h"
 #include "kernels_f16x3_one.h"
 #include "kernels_first.h"
+#include "kernels_res32.h"
 #include "kernels_sw.h"
 #include "kernels_project.h"
 
@@ -64,6 +65,8 @@ struct Op {
     size_t dev_wh32 = 0;          // offset (floats) of the fp16 weights in 32-channel chunks (precision mode f16, kernels_h32.h)
     bool h32_ok = false;
     size_t dev_ws = 0;            // offset (floats) of 1 / (power-of-two pre-scale of the split weights)
+    bool res_ok = false;          // 32 -> 32 stride-1 block: resident-weight persistent kernel (kernels_res32.h)
+    size_t dev_wres = 0;          // offset (floats) of its weight image [tap][hi,lo][g][cout][8 halves]
     bool first_direct = false;    // first conv block handled by conv3x3_first (reads the NCHW boundary tensor)
     size_t dev_wraw = 0;
 };
@@ -104,6 +107,7 @@ struct ts2d_engine {
     int tiled_inf = 0;            // the last predict_tiled produced an infinite aggregated logit (ts2d_engine_tiled_inf_flag)
     bool use_h32 = true;          // precision mode f16: 32-channel-chunk kernel (TS2D_H32=0 falls back to the 16-channel one)
     bool use_one = true;          // one-image-tile split kernel (TS2D_ONE=0 falls back to the generic one)
+    bool use_res = true;          // resident-weight kernel of the 32 -> 32 blocks (TS2D_RES=0 falls back)
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
     float* d_part = nullptr;
@@ -212,6 +216,10 @@ int build_program(ts2d_engine* e) {
             const size_t recs = op.stride == 1 ? (size_t)(ct / 16) * 9 : (size_t)(ct / 8) * 5;
             op.dev_wh = wo; wo = align_up(wo + recs * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);                  // 1 / scale, read by the kernel
+            if (op.stride == 1 && ct == 32 && op.cout == 32) {      // resident image of the 32 -> 32 block: [tap][hi,lo][g][cout][8 halves]
+                op.res_ok = true;
+                op.dev_wres = wo; wo = align_up(wo + 9 * 2 * 4 * 32 * 8 / 2, 64);
+            }
             if (op.stride == 1 && op.cin % 32 == 0 && op.cin_skip % 32 == 0) {      // [chunk32][column tile][tap][column][32 halves]
                 op.h32_ok = true;
                 op.dev_wh32 = wo; wo = align_up(wo + (size_t)(ct / 32) * 9 * op.cout * 16, 64);
@@ -328,6 +336,11 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                             const int chunk = ci / 16, cc = ci % 16, bn = co_n % 64 == 0 ? 64 : 32;
                             uint16_t* rec = d + ((((size_t)chunk * (co_n / bn) + co / bn) * 9 + tap) * bn + co % bn) * 32;
                             rec[cc] = hi; rec[16 + cc] = lo;
+                            if (op.res_ok) {
+                                uint16_t* rw = reinterpret_cast<uint16_t*>(out + op.dev_wres);
+                                rw[((((size_t)tap * 2 + 0) * 4 + ci / 8) * 32 + co) * 8 + ci % 8] = hi;
+                                rw[((((size_t)tap * 2 + 1) * 4 + ci / 8) * 32 + co) * 8 + ci % 8] = lo;
+                            }
                             if (op.h32_ok)          // same blocks with 32 real channels per record (the hi parts only)
                                 reinterpret_cast<uint16_t*>(out + op.dev_wh32)[((((size_t)(ci / 32) * (co_n / bn) + co / bn) * 9 + tap) * bn + co % bn) * 32 + ci % 32] = hi;
                         } else {       // K packed as 8 channels x 2 taps: k = 8 * (tap & 1) + (ci % 8) of k-step tap / 2
@@ -700,6 +713,39 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const int P = (g.PH * g.PW) << g.lgNIMG;
             const bool split = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT;
             if (f16 && !split) return fail(TS2D_ERR_INVALID, "op %s has no fp16 kernel (channel counts must be multiples of 16)", op.name.c_str());
+            if (conv && split && op.res_ok && e->use_res && e->use_one && src.scale != nullptr && op.skip < 0 && Ht % 8 == 0 && Wt % 32 == 0 &&
+                (size_t)Ht * Wt * 32 * 4 < ((size_t)1 << 31)) {
+                // 32 -> 32 stride-1 block on full 8 x 32 tiles: persistent kernel with the layer's weights resident in LDS
+                Res32Args ra{};
+                ra.src = src.data; ra.sc = src.scale; ra.sh = src.shift; ra.wres = wts + op.dev_wres; ra.bias = wts + op.dev_b;
+                ra.oscale = wts + op.dev_ws; ra.dst = dst.data; ra.part = e->d_part;
+                ra.B = B; ra.H = Ht; ra.W = Wt; ra.tiles_x = Wt / 32; ra.tiles_y = Ht / 8; ra.n_tiles = B * ra.tiles_x * ra.tiles_y;
+                ra.slope = a.leaky_slope;
+                // segment = the largest divisor of the tiles of one image that still leaves >= 2 workgroups per CU (or all tiles)
+                const int tpi_r = ra.tiles_x * ra.tiles_y, want = std::min(ra.n_tiles, 2 * e->num_cus);
+                int seg = 1;
+                for (int d = 1; d <= tpi_r; ++d) if (tpi_r % d == 0 && ra.n_tiles / d >= want) seg = d;
+                ra.seg = seg;
+                const int nbk = ra.n_tiles / seg;
+                TRY(prof_begin(e, op.name, st));
+                if (f16) {
+                    static std::atomic<uint64_t> done16{0};
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_res32<_Float16, 1>), done16));
+                    hipLaunchKernelGGL((conv3x3_res32<_Float16, 1>), dim3(nbk), dim3(kBlock), 9 * 4 * 512 + 4 * kResPS + 1024, st, ra);
+                } else {
+                    static std::atomic<uint64_t> done32{0};
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_res32<float, 3>), done32));
+                    hipLaunchKernelGGL((conv3x3_res32<float, 3>), dim3(nbk), dim3(kBlock), 9 * 2 * 4 * 512 + 8 * kResPS, st, ra);
+                }
+                HIP_TRY(hipGetLastError());
+                TRY(prof_end(e, st));
+                TRY(prof_begin(e, op.name + ".stats", st));
+                hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, tpi_r,
+                                   op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+                HIP_TRY(hipGetLastError());
+                TRY(prof_end(e, st));
+                continue;
+            }
             if (split && !conv) {
                 ca.n_ctiles = ca.N / 64;                       // N = 4 * Cout is a multiple of 128; each 32-column tile lies in one (a,b) tap
                 ca.lg_nct = lg_exact(ca.n_ctiles);
@@ -833,6 +879,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
         if (getenv("TS2D_H32")) e->use_h32 = getenv("TS2D_H32")[0] == '1';
         if (getenv("TS2D_ONE")) e->use_one = getenv("TS2D_ONE")[0] == '1';
+        if (getenv("TS2D_RES")) e->use_res = getenv("TS2D_RES")[0] == '1';
     }
     int rc = build_program(e);
     if (rc != TS2D_OK) { delete e; return rc; }

@@ -1,0 +1,281 @@
+// Level-0 block: Conv2d 3x3 stride 1, 32 -> 32 channels (enc0.c1 / dec0.c1 of the canonical net, 512x512 pixels per
+// slice - the layers that sit between the HBM and the MFMA roof), as a PERSISTENT kernel with the whole layer's weights RESIDENT
+// in LDS (32 x 32 x 9 x (hi + lo) fp16 = 36 KB) and ONE K step covering all 32 input channels:
+//   * v_mfma_f32_16x16x32_f16 (K = 32 = Cin).  On this chip the 16x16x32 shape holds a higher clock than 32x32x16 under load
+//     (scripts/probes/mfma_shape_probe.hip: +13..15 % FLOP/s at equal cycles per FLOP).  The product is issued TRANSPOSED,
+//     D[cout][pixel] = W^T[cout][ci] * X[ci][pixel]: a lane then holds 4 consecutive output channels of one pixel - one 16-byte NHWC
+//     store per 16x16 block instead of four 4-byte ones.
+//   * one staging phase and two barriers per 256-pixel tile (the generic kernel: two 16-channel chunks, each with its own weight
+//     staging and barrier pair); no weight traffic after the first tile of a workgroup.
+//   * the next tile's raw patch is prefetched into registers across the tile boundary (behind the MFMA phase and the epilogue).
+//   * a workgroup owns a SEGMENT of consecutive tiles of one image (column by column: consecutive tiles share their halo
+//     rows through L2).
+//   * LDS images are "k-group major": plane[g][pixel] of 16-byte slots (g = the 8-channel group a lane feeds to the MFMA),
+//     plane stride a multiple of 256 B.  A ds_read_b128 lane group (lanes {0-3,12-15} of one g + {4-11} of the next) then covers
+//     16 distinct slots of the 256-byte bank row with NO swizzle arithmetic, and every fragment address is lane base + immediate.
+// Arithmetic: split mode (NP = 3): x = hi + lo, w = whi + wlo, products wlo*xhi + whi*xlo + whi*xhi, fp32 accumulation over the
+// 9 taps x 32 channels of the layer (288-term chains; the generic kernel sums two 144-term chunks).  f16 mode (NP = 1): one product.
+#pragma once
+#include "kernels_f16x3.h"
+#include "kernels_h32.h"
+
+namespace ts2d {
+
+struct Res32Args {
+    const void* src; const float* sc; const float* sh;    // NHWC [B,H,W,32] activations of storage type ST; per-(n,c) scale / shift
+    const void* wres;      // resident weight image [tap 9][part hi,lo][g 4][cout 32][8 halves] (fp16; the f16 mode reads the hi parts)
+    const float* bias;     // [32]
+    const float* oscale;   // 1 / (power-of-two weight pre-scale)
+    void* dst;             // raw NHWC [B,H,W,32] output (ST)
+    float* part;           // InstanceNorm partials [n][tile (column-major index inside the image)][32][2]
+    int B, H, W;           // H % 8 == 0, W % 32 == 0
+    int tiles_x, tiles_y;  // W / 32, H / 8
+    int n_tiles;           // B * tiles_x * tiles_y
+    int seg;               // tiles per workgroup segment; divides tiles_x * tiles_y (a segment never leaves its image)
+                           // (the statistics stay per TILE: a slice computes bit-identically alone or in a batch)
+    float slope;
+};
+
+constexpr int kResPW = 34, kResP = 340, kResPS = 352 * 16;      // patch 10 x 34 pixels; plane stride (bytes)
+
+template <typename ST, int NP>
+__global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
+    constexpr int NPP = NP == 3 ? 2 : 1;                   // fp16 parts per value (hi, lo)
+    constexpr int WB = 9 * NPP * 4 * 512;                  // resident weights (bytes)
+    constexpr int NL = sizeof(ST) == 4 ? 2 : 1;            // 16-byte loads per staging unit (8 channels)
+    constexpr int NU = 6;                                  // staging units per thread: 6 x 64 pixels >= 340
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;                // MFMA lane roles: row/column index, k-group
+
+    // ---- work list: segment s = tiles [s * seg, (s + 1) * seg), tiles numbered column by column inside an image
+    //      (t = (n * tiles_x + txi) * tiles_y + tyi); seg divides tiles_x * tiles_y, so a segment lies in one image.
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int t0 = (int)blockIdx.x * a.seg;
+    if (t0 >= a.n_tiles) return;
+    const int t1 = t0 + a.seg;
+    const int n = t0 / tpi;                                // the segment's image
+    int trem = t0 - n * tpi;
+    int txi = trem / a.tiles_y, tyi = trem - txi * a.tiles_y;
+
+    // ---- resident weights: one linear copy of the pre-arranged image (once per workgroup)
+    {
+        const uint4* wsrc = reinterpret_cast<const uint4*>(a.wres);
+#pragma unroll
+        for (int k = 0; k < (WB / 16 + kBlock - 1) / kBlock; ++k) {       // (f16 mode: the hi parts only - every other 2-KB block of the image)
+            const int sl = tid + k * kBlock;
+            if (sl < WB / 16) *reinterpret_cast<uint4*>(smem8 + sl * 16) = wsrc[NPP == 2 ? sl : (sl >> 7) * 256 + (sl & 127)];
+        }
+    }
+    unsigned char* sP = smem8 + WB;                        // patch planes [part][g][pixel] x 16 B
+    // cross-wave statistics scratch: 64-byte pieces in the 12 unused slots at the end of each patch plane (split mode: the
+    // two workgroups of a CU use all 160 KiB), or behind the planes (f16 mode)
+    auto scratch = [&](int ww, int gg) -> float* {
+        if (NPP == 2) return reinterpret_cast<float*>(sP + (2 * ww + (gg >> 1)) * kResPS + kResP * 16 + (gg & 1) * 64);
+        return reinterpret_cast<float*>(sP + NPP * 4 * kResPS + (ww * 4 + gg) * 64);
+    };
+
+    // ---- staging plan.  Unit (it): pixel p = 64 it + 16 w + (lane & 7) + 8 (lane >> 5), channel group sg = (lane >> 3) & 3:
+    //      one wave instruction covers 16 whole pixels (every byte of their 128-byte records), 8 consecutive lanes write 8
+    //      consecutive 16-byte slots of one plane (conflict-free ds_write_b128).
+    const int sg = (lane >> 3) & 3, pl = (lane & 7) + 8 * (lane >> 5);
+    unsigned rel[NU];          // byte offset of the unit's 8 channels relative to the patch origin (ty0 - 1, tx0 - 1)
+    unsigned emask = 0;        // per unit 4 bits: patch row 0 / row 9 / column 0 / column 33 (the padding candidates)
+#pragma unroll
+    for (int it = 0; it < NU; ++it) {
+        const int p = 64 * it + 16 * w + pl;
+        const int py = p / kResPW, px = p - py * kResPW;
+        rel[it] = (unsigned)(((py * a.W + px) * 32 + 8 * sg) * (int)sizeof(ST));
+        if (p < kResP) emask |= ((py == 0 ? 1u : 0u) | (py == 9 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == kResPW - 1 ? 8u : 0u)) << (4 * it);
+    }
+    const bool last_unit = 64 * (NU - 1) + 16 * w + pl < kResP;          // unit NU-1 exists for this thread
+    const int swr = sg * kResPS + (16 * w + pl) * 16;      // LDS write address of unit 0 (hi part); unit it: + 1024 it
+
+    const size_t img_bytes = (size_t)a.H * a.W * 32 * sizeof(ST);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.src)) + (size_t)n * img_bytes,
+                                                      0, (int)img_bytes, 0x00020000);
+    u32x4 pv[NU][NL];
+    auto prefetch = [&](int ptx, int pty) {
+        // origin may lie one row / column outside the image: unsigned wrap-around is fine, the affected units are padding
+        const unsigned org = (unsigned)((((pty * 8 - 1) * a.W + (ptx * 32 - 1)) * 32) * (int)sizeof(ST));
+#pragma unroll
+        for (int it = 0; it < NU; ++it)
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                pv[it][l] = __builtin_amdgcn_raw_buffer_load_b128(rs, org + rel[it] + 16 * l, 0, 0);
+    };
+    prefetch(txi, tyi);
+
+    // ---- lane constants of the MFMA phase and the epilogue
+    const int wbase = g * 512 + j * 16;                                    // weight fragment: + ((tap * NPP + part) * 4) * 512 + cb * 256
+    const int pbase = WB + g * kResPS + (2 * w * kResPW + j) * 16;        // patch fragment: + part * 4 * PS + ((pb >> 1) + dy) * 34 * 16 + (16 (pb & 1) + dx) * 16
+    float bv[2][4];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[cb][i] = a.bias[cb * 16 + 4 * g + i];
+    const float oscale = *a.oscale;
+    const unsigned vst = (unsigned)((j * 32 + 4 * g) * (int)sizeof(ST));   // store: lane part of the byte offset
+    const _Float16 slope_h = (_Float16)a.slope;
+    const unsigned slope2 = (unsigned)__builtin_bit_cast(unsigned short, slope_h) * 0x10001u;
+    const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.dst) + (size_t)n * img_bytes, 0, (int)img_bytes, 0x00020000);
+    // scale / shift of this thread's 8 staging channels (image n)
+    const float* ps = a.sc + (size_t)n * 32 + 8 * sg; const float* pt = a.sh + (size_t)n * 32 + 8 * sg;
+    const f32x4 nsa = *reinterpret_cast<const f32x4*>(ps), nsb = *reinterpret_cast<const f32x4*>(ps + 4);
+    const f32x4 nta = *reinterpret_cast<const f32x4*>(pt), ntb = *reinterpret_cast<const f32x4*>(pt + 4);
+    const f32x4 slope4 = f32x4{a.slope, a.slope, a.slope, a.slope};
+
+    for (int t = t0; t < t1; ++t) {
+        // ---- patch: InstanceNorm + LeakyReLU on the fly, split into fp16 hi / lo, written k-group major
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+            if (it < NU - 1 || last_unit) {
+                unsigned char* d = sP + swr + it * 1024;
+                if constexpr (sizeof(ST) == 4) {
+                    f32x4 va = __builtin_bit_cast(f32x4, pv[it][0]), vb = __builtin_bit_cast(f32x4, pv[it][NL - 1]);
+                    va = va * nsa + nta; vb = vb * nsb + ntb;
+                    const f32x4 na = va * slope4, nb2 = vb * slope4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { va[e] = fmaxf(va[e], na[e]); vb[e] = fmaxf(vb[e], nb2[e]); }      // LeakyReLU (0 < slope < 1)
+                    uint4 hi, lo;
+                    split_hi_lo_8(va, vb, hi, lo);
+                    *reinterpret_cast<uint4*>(d) = hi;
+                    if (NPP == 2) *reinterpret_cast<uint4*>(d + 4 * kResPS) = lo;
+                } else {
+                    uint4 x = uint4{pv[it][0][0], pv[it][0][1], pv[it][0][2], pv[it][0][3]};
+                    *reinterpret_cast<uint4*>(d) = norm_lrelu_8(x, nsa, nsb, nta, ntb, slope2);
+                }
+            }
+        }
+        // tiles on the image border: the patch rows / columns outside the image are zero padding (AFTER norm + activation)
+        const unsigned edge = (tyi == 0 ? 1u : 0u) | (tyi == a.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) | (txi == a.tiles_x - 1 ? 8u : 0u);
+        if (edge) {                                        // wave-uniform; 15 % of the tiles of a 512 x 512 image
+            const unsigned hit = emask & (edge * 0x111111u);
+#pragma unroll
+            for (int it = 0; it < NU; ++it)
+                if (hit & (0xFu << (4 * it))) {
+                    unsigned char* d = sP + swr + it * 1024;
+                    *reinterpret_cast<uint4*>(d) = uint4{0u, 0u, 0u, 0u};
+                    if (NPP == 2) *reinterpret_cast<uint4*>(d + 4 * kResPS) = uint4{0u, 0u, 0u, 0u};
+                }
+        }
+        __syncthreads();                                   // patch (and, first tile, the weights) visible to every wave
+
+        // ---- next tile of the segment (one row down, or the top of the next column): prefetch its raw patch behind the MFMAs
+        int ntx = txi, nty = tyi + 1;
+        if (nty == a.tiles_y) { nty = 0; ntx = txi + 1; }
+        if (t + 1 < t1) prefetch(ntx, nty);
+
+        // ---- 9 taps x (2 channel blocks x 4 pixel blocks) x NP products
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            half8 fw[2][NPP], fx[4][NPP];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int pt2 = 0; pt2 < NPP; ++pt2)
+                    fw[cb][pt2] = *reinterpret_cast<const half8*>(smem8 + wbase + ((tap * NPP + pt2) * 4) * 512 + cb * 256);
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+                for (int pt2 = 0; pt2 < NPP; ++pt2)
+                    fx[pb][pt2] = *reinterpret_cast<const half8*>(smem8 + pbase + pt2 * 4 * kResPS + (((pb >> 1) + dy) * kResPW + 16 * (pb & 1) + dx) * 16);
+            if constexpr (NP == 3) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb][1], fx[pb][0], acc[cb][pb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb][0], fx[pb][1], acc[cb][pb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb][0], fx[pb][0], acc[cb][pb], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- epilogue: lane = pixel j of block pb, channels 16 cb + 4 g .. + 3: one 16-byte (fp16: 8-byte) store per block
+        f32x4 ov[2][4];
+        {
+            float ss[2][4], qq[2][4];                      // (sum, sum of squares) of this lane's 4 pixels per channel
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ss[cb][i] = 0.f; qq[cb][i] = 0.f; }
+            const unsigned tile_off = (unsigned)((((tyi * 8 + 2 * w) * a.W + txi * 32) * 32) * (int)sizeof(ST));      // scalar
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const unsigned soff = tile_off + (unsigned)((((pb >> 1) * a.W + 16 * (pb & 1)) * 32 + cb * 16) * (int)sizeof(ST));
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[cb][pb][i], oscale, bv[cb][i]);
+                    // gfx950 hazard (found with this kernel): a VALU write to the data registers of a 128-bit buffer store two
+                    // instructions behind it reaches the stored data (last dword, lanes 12-15 of each lane row) - hipcc's one
+                    // wait state is not enough, and with an SGPR soffset it inserts none.  The offset therefore rides in the VGPR
+                    // and the stored vectors stay live (asm use below) until the end of the tile.
+                    if constexpr (sizeof(ST) == 4) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsd, vst + soff, 0, 0);
+                    } else {
+                        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        half4 hv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { hv[i] = (_Float16)v[i]; v[i] = (float)hv[i]; }      // statistics of what is stored
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rsd, vst + soff, 0, 0);
+                    }
+                    ov[cb][pb] = v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { ss[cb][i] += v[i]; qq[cb][i] = __builtin_fmaf(v[i], v[i], qq[cb][i]); }
+                }
+            // sum over the 16 pixels of the lane row (DPP row rotations: every lane of the row ends up with the total)
+            float* sc4 = scratch(w, g);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float s = ss[cb][i], q = qq[cb][i];
+#define TS2D_ROR_ADD(X, N) X += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, X), 0x120 + N, 0xF, 0xF, true))
+                    TS2D_ROR_ADD(s, 8); TS2D_ROR_ADD(q, 8); TS2D_ROR_ADD(s, 4); TS2D_ROR_ADD(q, 4);
+                    TS2D_ROR_ADD(s, 2); TS2D_ROR_ADD(q, 2); TS2D_ROR_ADD(s, 1); TS2D_ROR_ADD(q, 1);
+#undef TS2D_ROR_ADD
+                    ss[cb][i] = s; qq[cb][i] = q;
+                }
+                if (j == 0) {                              // 4 lanes per wave (g = 0..3): channels 16 cb + 4 g + i
+                    *reinterpret_cast<f32x4*>(sc4 + cb * 8) = f32x4{ss[cb][0], ss[cb][1], ss[cb][2], ss[cb][3]};
+                    *reinterpret_cast<f32x4*>(sc4 + cb * 8 + 4) = f32x4{qq[cb][0], qq[cb][1], qq[cb][2], qq[cb][3]};
+                }
+            }
+        }
+        __syncthreads();                                   // every wave is done with the patch; the scratch is complete
+        if (tid < 64) {                                    // tile partial (fixed order over the 4 waves)
+            const int co = tid >> 1, which = tid & 1, cb = co >> 4, gg = (co >> 2) & 3, i = co & 3;
+            float tot = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) tot += scratch(ww, gg)[cb * 8 + which * 4 + i];
+            a.part[((size_t)n * tpi + (t - n * tpi)) * 64 + tid] = tot;
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) asm volatile("" :: "v"(ov[cb][pb]));      // store data registers untouched up to here
+        txi = ntx; tyi = nty;
+    }
+
+}
+
+}  // namespace ts2d
