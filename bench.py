@@ -9,6 +9,12 @@ One "step" = one forward pass of the hot path (the whole PlainConvUNet, input NC
 over one batch of 64 synthetic slices per GPU, inputs already resident in HBM.  Slices shard over ranks with no
 data-path collective (weak scaling); weights are broadcast once from rank 0 with RCCL before the timed region.
 Rank 0 prints ONE JSON line.
+
+Other BASELINE configurations (same contract, ONE JSON line each; `config.workload` names the configuration):
+    python bench.py --workload config3          five ts2d-v2 sub-models (117 labels) on one batch of 128, 16-bit mode
+    python bench.py --workload config4 [--stream 10000]   (N ranks) contiguous blocks of a 10k-slice stream generated on the
+                                                device from (seed, slice index); strong scaling; weight broadcast reported
+The default (config 2) line of an N > 1 run also carries the config-4 result as `stream_10k`.
 """
 from __future__ import annotations
 
@@ -69,6 +75,86 @@ def cpu_baseline(arch, sd, budget_s: float = 20.0, check=None):
                       f'{torch.get_num_threads()} threads'}, err
 
 
+def csrc_hash() -> str:
+    """Hash of the kernel sources: profiles/pmc_traffic.json is stamped with it so that a stale PMC figure is not reported
+    against kernels it was not measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'totalsegmentator2d_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.h', '.hip')):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def oracle_check(arch, sd, x4, logits4, mask4):
+    """Live parity of the metric's own outputs: `x4` slices of the timed batch through the torch-CPU oracle."""
+    from oracle import torch_oracle as O
+    from totalsegmentator2d_amd.engine import unpack_mask
+    errs, flips, bits = [], 0, 0
+    for i in range(x4.shape[0]):
+        ref = O.unet_forward(arch, sd, x4[i:i + 1]).numpy()
+        errs.append(float(np.abs(ref - logits4[i:i + 1]).max()))
+        m_ref = O.logits_to_mask(ref).numpy()
+        m_gpu = unpack_mask(mask4[i:i + 1], x4.shape[-1])
+        flips += int((m_ref != m_gpu).sum()); bits += int(m_ref.size)
+    return errs, flips, bits
+
+
+def run_config3(args, torch, dev, local_rank):
+    """BASELINE config 3: full ts2d-v2 (5 sub-models, 117 labels), batch 128, one MI355X, 16-bit mode."""
+    from totalsegmentator2d_amd import parallel, weights
+    from totalsegmentator2d_amd.arch import UNetArch
+    from totalsegmentator2d_amd.submodels import SubModelSet, TS2D_V2_HEADS
+    B = 128 if args.batch == 64 else args.batch
+    models = []
+    for i, mid in enumerate(sorted(TS2D_V2_HEADS)):
+        a = UNetArch.canonical(num_classes=TS2D_V2_HEADS[mid])
+        models.append((mid, a, weights.pack_blob(a, weights.synthetic_state_dict(a, seed=i + 1))))
+    x = parallel.synth_slices(local_rank, 0, 0, B, (2, 512, 512))
+    with SubModelSet(models, device=local_rank, precision=args.precision) as ms:
+        ms.reserve(B, 512, 512)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        masks = ms.forward_masks(x, stream=stream)
+        for _ in range(max(args.warmup - 1, 0)):
+            ms.forward_masks(x, masks, stream=stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ms.forward_masks(x, masks, stream=stream)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        merged = SubModelSet.merge(masks)
+        torch.cuda.synchronize(dev)
+        work = sum(e.arch.work(512, 512)['flops'] for e in ms.engines)
+        out = {'metric': '2-ch 512x512 slices/sec', 'value': round(B * args.steps / el, 2), 'unit': 'slices/s', 'n_gpus': 1,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 3), 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None,
+               'dtype': {'f16': 'f16 storage + f16 MFMA, f32 accumulate/statistics', 'split': 'f32 storage, 3x fp16-split MFMA', 'exact': 'f32'}[args.precision],
+               'data': 'synthetic',
+               'config': {'workload': 'BASELINE configs[2]: full ts2d-v2 (5 sub-models, K = 18/23/24/26/26 -> 117 labels), batch=128, '
+                                      '1xMI355X, 16-bit mode (fp16 storage; the config says bf16 - DESIGN.md section 4), packed masks out',
+                          'batch_per_gpu': B, 'sub_models': ms.ids, 'labels': int(merged.shape[1]), 'H': 512, 'W': 512,
+                          'gflop_per_slice_all_models': round(work / 1e9, 1)},
+               'sub_model_forwards_per_s': round(5 * B * args.steps / el, 1), 'tflops': round(B * args.steps / el * work / 1e12, 1),
+               'precision_mode': args.precision}
+    print(json.dumps(out), flush=True)
+
+
+def run_config4(args, torch, dev, engine, rank, world, total, seed=0, batch=64):
+    """BASELINE config 4 on this rank: its contiguous block of the `total`-slice stream (generated on the device beforehand)."""
+    from totalsegmentator2d_amd import parallel
+    engine.set_precision(args.precision)
+    lo, hi, _, _ = parallel.run_slice_stream(engine, seed, min(total, 2 * batch * world), rank, world, batch=batch, keep_masks=False)   # warm-up
+    if world > 1 or os.environ.get('TS2D_FORCE_DIST') == '1':
+        import torch.distributed as dist
+        dist.barrier()
+    lo, hi, masks, dt = parallel.run_slice_stream(engine, seed, total, rank, world, batch=batch, keep_masks=True)
+    el = parallel.max_over_ranks(dt)
+    return {'slices': total, 'block_of_rank0': [lo, hi], 'seconds': round(el, 4), 'value': round(total / el, 2), 'unit': 'slices/s',
+            'batch': batch, 'mask_words_kept': int(masks.numel()) if masks is not None else 0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -77,10 +163,16 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='slices per GPU per step (config 2: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
-    ap.add_argument('--precision', choices=('split', 'exact', 'f16'), default='split',
+    ap.add_argument('--workload', choices=('config2', 'config3', 'config4'), default='config2')
+    ap.add_argument('--stream', type=int, default=None, help='config 4: total slices of the synthetic stream (default 10000)')
+    ap.add_argument('--precision', choices=('split', 'exact', 'f16'), default=None,
                     help="split: fp16 hi/lo x3 MFMA with fp32 accumulation (fp32-equivalent accuracy, default); exact: fp32 MFMA; "
                          "f16: fp16 storage + one fp16 MFMA product (BASELINE configs 3/5, outside the fp32 parity tolerance)")
     args = ap.parse_args()
+    if args.stream is not None and args.workload == 'config2':
+        args.workload = 'config4'
+    if args.precision is None:
+        args.precision = 'f16' if args.workload == 'config3' else 'split'
 
     import torch
     import torch.distributed as dist
@@ -97,6 +189,12 @@ def main():
         parallel.init_process_group('nccl')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+
+    if args.workload == 'config3':
+        if world != 1:
+            raise SystemExit('config 3 is a one-GPU configuration')
+        run_config3(args, torch, dev, local_rank)
+        return
 
     arch = UNetArch.canonical(input_channels=2, num_classes=18)            # one ts2d-v2 sub-model (cardiac, K = 18)
     B, H, W = args.batch, 512, 512
@@ -123,6 +221,29 @@ def main():
             la, _ = engine.forward(xa); lb, _ = replica.forward(xa); torch.cuda.synchronize(dev)
             assert torch.equal(la, lb), 'replica filled through the broadcast hook differs'
             replica.close()
+    if args.workload == 'config4':
+        total = args.stream if args.stream is not None else 10000
+        r4 = run_config4(args, torch, dev, engine, rank, world, total, batch=B)
+        if rank == 0:
+            work = arch.work(H, W)
+            out = {'metric': '2-ch 512x512 slices/sec', 'value': r4['value'], 'unit': 'slices/s', 'n_gpus': world,
+                   'steps': (total // world + B - 1) // B, 'warmup': 2, 'ms_per_step': round(r4['seconds'] / max(1, (total // world + B - 1) // B) * 1e3, 3),
+                   'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+                   'dtype': 'f32 storage/accumulate, products as 3x fp16-split MFMA (f16x3)' if args.precision == 'split' else args.precision,
+                   'data': 'synthetic',
+                   'config': {'workload': f'BASELINE configs[3]: {world}xMI355X slice-batch sharding, synthetic {total}-slice stream generated on the '
+                                          'device from (seed, slice index), contiguous blocks per rank, RCCL weight broadcast before the timed region, '
+                                          'packed masks of the whole stream kept', 'stream_slices': total, 'batch_per_step': B,
+                              'parallelism': f'slice-dp{world}', 'gflop_per_slice': round(work['flops'] / 1e9, 2)},
+                   'weight_broadcast_ms': None if bcast_ms is None else round(bcast_ms, 2), 'precision_mode': args.precision,
+                   'tflops': round(r4['value'] * work['flops'] / 1e12, 2)}
+            print(json.dumps(out), flush=True)
+        engine.close()
+        if multi:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn(B, 2, H, W, device=dev, generator=gen)                 # synthetic N(0,1) = post-z-score statistics
     logits = torch.empty(B, arch.num_classes, H, W, device=dev)
@@ -156,6 +277,12 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
 
+    stream_res = None
+    if world > 1:            # config 4 on the same ranks (outside the timed region above): 10k-slice stream, contiguous blocks
+        if profile:
+            engine.set_profiling(False)
+        stream_res = run_config4(args, torch, dev, engine, rank, world, 10000, batch=B)
+
     if rank == 0:
         work = arch.work(H, W)
         ms_per_step = elapsed / args.steps * 1e3
@@ -173,6 +300,8 @@ def main():
         }
         if bcast_ms is not None:
             out['weight_broadcast_ms'] = round(bcast_ms, 2)
+        if stream_res is not None:
+            out['stream_10k'] = dict(stream_res, workload='BASELINE configs[3]: 10k-slice stream, contiguous blocks per rank (strong scaling)')
         split = args.precision == 'split'
         out['dtype'] = {'split': 'f32 storage/accumulate, products as 3x fp16-split MFMA (f16x3)', 'exact': 'f32',
                         'f16': 'f16 storage + f16 MFMA, f32 accumulate/statistics (NOT within the fp32 parity tolerance)'}[args.precision]
@@ -187,16 +316,18 @@ def main():
             conv_flops = sum(per.values()) * B
             achieved = conv_flops / (conv_ms * 1e-3) / 1e12
             peak = {'split': PEAK_F16_MFMA_TFLOPS / 3.0, 'exact': PEAK_FP32_MFMA_TFLOPS, 'f16': PEAK_F16_MFMA_TFLOPS}[args.precision]
-            traffic = None
+            traffic, traffic_stale = None, None
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(f'conv3x3_s1_{args.precision}_hbm_bytes_per_launch_avg')
+                    pj = json.load(open(pmc))
+                    traffic_stale = pj.get('csrc_hash') != csrc_hash()          # measured on other kernel sources: do not report it
+                    traffic = None if traffic_stale else pj.get(f'conv3x3_s1_{args.precision}_hbm_bytes_per_launch_avg')
                 except Exception:
                     traffic = None
             all3 = {o['name'] for o in prog if o['op'] == OP_CONV3X3}
             out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                               'frac': round(achieved / peak, 4), 'traffic': traffic,
+                               'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_stale': traffic_stale,
                                'kernel': {'split': 'conv3x3_f16x3_one (18) + conv3x3_f16x3 (4)', 'f16': 'conv3x3_h32 (18) + conv3x3_f16x3<f16> (4)',
                                           'exact': 'conv_mfma_f32<9,1,16,*>'}[args.precision] + f' ({len(per)} launches/step)',
                                'peak_note': ('dense fp16 MFMA 2500 TFLOP/s / 3 products per MAC' if split else 'fp32 MFMA 32x32x2'),
@@ -224,6 +355,17 @@ def main():
                 step()
             torch.cuda.synchronize(dev)
             out['other_mode'] = {'precision_mode': other, 'value': round(B * max(2, args.steps // 2) / (time.perf_counter() - t1), 2), 'unit': 'slices/s'}
+            if profile and other == 'exact':
+                # the strict-fp32 number (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 FMA chain) with its own roofline block
+                engine.set_profiling(True)
+                step(); torch.cuda.synchronize(dev)
+                ot = engine.op_times()
+                engine.set_profiling(False)
+                ems = sum(v for k, v in ot.items() if k in per)
+                each = conv_flops / (ems * 1e-3) / 1e12
+                out['other_mode']['roofline'] = {'bound': 'mfma', 'achieved': round(each, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                                 'frac': round(each / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                                                 'kernel': f'conv_mfma_f32<9,1,16,*> ({len(per)} launches/step)', 'kernel_ms_per_step': round(ems, 3)}
             if split:                                                   # third mode, for the record (configs 3/5 arithmetic)
                 engine.set_precision('f16')
                 step(); torch.cuda.synchronize(dev)
@@ -236,10 +378,18 @@ def main():
             engine.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
             step(); torch.cuda.synchronize(dev)
-            chk = (x[:1].cpu().numpy(), logits[:1].cpu().numpy())
-            out['cpu_baseline'], err = cpu_baseline(arch, sd, check=chk)
-            out['logit_max_abs_err_vs_oracle'] = {'value': err, 'tol': 1e-4, 'slices_checked': 1,
-                                                  'note': 'live check in the cpu_baseline leg; full parity: pytest -m gpu'}
+            idx = [0, B // 3, (2 * B) // 3, B - 1] if B >= 4 else list(range(B))
+            import torch as _t
+            sel = _t.tensor(idx, device=dev)
+            errs, flips, bits = oracle_check(arch, sd, x[sel].cpu().numpy(), logits[sel].cpu().numpy(), mask[sel].cpu().numpy())
+            out['cpu_baseline'], _ = cpu_baseline(arch, sd)
+            out['logit_max_abs_err_vs_oracle'] = {'value': max(errs), 'per_slice': [round(e, 8) for e in errs], 'tol': 1e-4,
+                                                  'slices_checked': len(idx), 'slice_indices': idx,
+                                                  'note': 'outputs of the timed batch vs the torch-CPU oracle; full parity: pytest -m gpu'}
+            # masks are bit-exact as a function of the engine's OWN logits (tests); against the oracle end to end a pixel whose
+            # |logit| is below the logit error can fall on the other side of the threshold - reported, not hidden
+            out['mask_disagree_vs_oracle'] = {'bits_differing': flips, 'bits_checked': bits, 'fraction': flips / max(bits, 1),
+                                              'slices_checked': len(idx)}
         print(json.dumps(out), flush=True)
     engine.close()
     if multi:

@@ -138,6 +138,15 @@ int ts2d_engine_tiled_inf_flag(const ts2d_engine* e);
 int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
                          long long sy, long long sx, long long base, float* out_max, float* out_mean);
 
+/* Synthetic slice stream on the device (BASELINE config 4: "synthetic 10k-slice stream", generated per rank from (seed, slice
+ * index) so that no host transfer skews the timing).  Writes n_elements fp32 values, approximately N(0,1), to device memory:
+ * element i of the call = element (first_element + i) of the stream identified by `key`; a value depends on (key, element index)
+ * only, so every rank can produce any block of the stream, and it is bit-identical to the host generator
+ * totalsegmentator2d_amd/prng.py (key = prng.key(seed, stream)).  Asynchronous on `stream` (hipStream_t as void*, NULL = default).
+ * The reference has no counterpart (it reads files); the bench and the multi-GPU tests are the callers. */
+int ts2d_synth_slices(int device, unsigned long long key, unsigned long long first_element, unsigned long long n_elements,
+                      float* out_device, void* stream);
+
 /* Pre-allocate the activation workspace for (B, H, W) (reference warm-up contract: a zero patch is pushed through
  * the predictor once at start-up, prediction_worker.py:74-96,136-138). */
 int ts2d_engine_reserve(ts2d_engine* e, int B, int H, int W);

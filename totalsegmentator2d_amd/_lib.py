@@ -20,7 +20,7 @@ PRECISION_F16 = 2
 
 # every symbol include/ts2d_engine.h declares
 SYMBOLS = ('ts2d_engine_create', 'ts2d_engine_load_weights', 'ts2d_engine_weight_buffer', 'ts2d_engine_weights_ready',
-           'ts2d_engine_forward', 'ts2d_engine_predict_tiled', 'ts2d_engine_tiled_inf_flag', 'ts2d_engine_set_tile_dtype', 'ts2d_project_coronal', 'ts2d_engine_reserve', 'ts2d_engine_set_precision', 'ts2d_engine_set_profiling', 'ts2d_engine_num_ops',
+           'ts2d_engine_forward', 'ts2d_engine_predict_tiled', 'ts2d_engine_tiled_inf_flag', 'ts2d_engine_set_tile_dtype', 'ts2d_project_coronal', 'ts2d_synth_slices', 'ts2d_engine_reserve', 'ts2d_engine_set_precision', 'ts2d_engine_set_profiling', 'ts2d_engine_num_ops',
            'ts2d_engine_op_name', 'ts2d_engine_op_times', 'ts2d_engine_debug_tensor', 'ts2d_engine_device_bytes', 'ts2d_engine_destroy',
            'ts2d_last_error', 'ts2d_abi_version')
 
@@ -83,6 +83,8 @@ def load():
     lib.ts2d_project_coronal.restype = c.c_int
     lib.ts2d_project_coronal.argtypes = [c.c_int, c.c_void_p, c.c_size_t, c.c_int, c.c_int, c.c_int, c.c_int, c.c_longlong, c.c_longlong,
                                          c.c_longlong, c.c_longlong, c.c_void_p, c.c_void_p]
+    lib.ts2d_synth_slices.restype = c.c_int
+    lib.ts2d_synth_slices.argtypes = [c.c_int, c.c_ulonglong, c.c_ulonglong, c.c_ulonglong, c.c_void_p, c.c_void_p]
     lib.ts2d_engine_reserve.restype = c.c_int
     lib.ts2d_engine_reserve.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int]
     lib.ts2d_engine_set_precision.restype = c.c_int

@@ -1072,6 +1072,22 @@ int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dty
     return TS2D_OK;
 }
 
+int ts2d_synth_slices(int device, unsigned long long key, unsigned long long first_element, unsigned long long n_elements,
+                      float* out_device, void* stream) {
+    if (!out_device) return fail(TS2D_ERR_INVALID, "ts2d_synth_slices: null output");
+    if (n_elements == 0) return TS2D_OK;
+    if (n_elements > (1ull << 40)) return fail(TS2D_ERR_INVALID, "ts2d_synth_slices: %llu elements in one call", n_elements);
+    HIP_TRY(hipSetDevice(device));
+    const unsigned long long per = 1ull << 30;                      // <= 2^30 elements per launch (grid of 2^22 blocks)
+    for (unsigned long long o = 0; o < n_elements; o += per) {
+        const unsigned long long m = std::min(per, n_elements - o);
+        hipLaunchKernelGGL(synth_normal, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           out_device + o, key, first_element + o, m);
+        HIP_TRY(hipGetLastError());
+    }
+    return TS2D_OK;
+}
+
 int ts2d_engine_set_profiling(ts2d_engine* e, int enable) {
     if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_profiling: null engine");
     e->profiling = enable != 0;

@@ -28,4 +28,31 @@ __global__ void project_coronal(const T* __restrict__ vol, int nz, int ny, int n
     }
 }
 
+// Synthetic slice stream (BASELINE config 4: "synthetic 10k-slice stream ... generated on device per rank from (seed, slice_index)"):
+// the portable counter-based generator of totalsegmentator2d_amd/prng.py restated for the device - splitmix64 of the element
+// counter, eight 16-bit uniforms summed (Irwin-Hall) and standardised in double, rounded once to float.  Element e of the stream
+// depends on (key, e) only, so any rank produces the bits of any slice; integer arithmetic + one IEEE double multiply: the values
+// are bit-identical to prng.normal_f32(seed, stream, ..., offset) on the host (tests/test_gpu_stream.py).
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void synth_normal(float* __restrict__ out, unsigned long long key, unsigned long long first, unsigned long long n) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long idx = first + i;
+    const unsigned long long h1 = splitmix64((idx * 2ull) * 0xD1342543DE82EF95ull + key);
+    const unsigned long long h2 = splitmix64((idx * 2ull + 1ull) * 0xD1342543DE82EF95ull + key);
+    long long s = 0;
+#pragma unroll
+    for (int sh = 0; sh < 64; sh += 16) s += (long long)((h1 >> sh) & 0xFFFFull) + (long long)((h2 >> sh) & 0xFFFFull);
+    // 1 / (65536 * sqrt(8 / 12)): the same double constant as prng._IH_SCALE (passed as its bit pattern: no libm on either side)
+    const double scale = __longlong_as_double(0x3EF3988E1409212Ell);
+    out[i] = (float)((double)(s - 4 * 65535) * scale);
+}
+
 }  // namespace ts2d

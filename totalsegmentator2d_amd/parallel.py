@@ -97,3 +97,51 @@ def max_over_ranks(value: float) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ----------------------------------------------------------------------------- BASELINE config 4: sharded slice stream
+STREAM_ID = 1000          # prng stream of the synthetic slices (tests/cases.py::make_input uses the same stream)
+
+
+def synth_slices(device: int, seed: int, first_slice: int, n_slices: int, shape_chw, out=None, stream: int = 0):
+    """Slices [first_slice, first_slice + n_slices) of the synthetic stream `seed`, generated ON THE DEVICE (C-ABI
+    ts2d_synth_slices) into a torch CUDA tensor [n_slices, C, H, W]; bit-identical to
+    ``prng.normal_f32(seed, STREAM_ID, (n_slices, C, H, W), offset=first_slice * C * H * W)`` on the host."""
+    import ctypes
+    import torch
+    from . import _lib, prng
+    C, H, W = (int(v) for v in shape_chw)
+    per = C * H * W
+    if out is None:
+        out = torch.empty((n_slices, C, H, W), dtype=torch.float32, device=torch.device('cuda', device))
+    lib = _lib.load()
+    _lib.check(lib.ts2d_synth_slices(int(device), prng.key(seed, STREAM_ID), first_slice * per, n_slices * per,
+                                     out.data_ptr(), ctypes.c_void_p(stream)), 'ts2d_synth_slices')
+    return out
+
+
+def run_slice_stream(engine, seed: int, total_slices: int, rank: int, world: int, shape_chw=(2, 512, 512), batch: int = 64,
+                     keep_masks: bool = True):
+    """Config 4 on one rank: the contiguous block ``shard_range(total_slices, rank, world)`` of the stream, generated on the
+    device BEFORE the timed region (inputs resident in HBM), pushed through the engine in batches of `batch`, packed masks kept
+    for the whole block.  Returns (lo, hi, masks int32 [hi-lo, K, H, W/32] or None, seconds of the timed region).  No
+    data-path collective: the caller reduces the time with max_over_ranks."""
+    import time
+    import torch
+    lo, hi = shard_range(total_slices, rank, world)
+    n = hi - lo
+    C, H, W = shape_chw
+    K = engine.arch.num_classes
+    dev = torch.device('cuda', engine.device)
+    x = synth_slices(engine.device, seed, lo, n, shape_chw) if n else torch.empty((0, C, H, W), device=dev)
+    masks = torch.empty((n, K, H, W // 32), dtype=torch.int32, device=dev) if keep_masks else None
+    scratch = None if keep_masks else torch.empty((min(batch, max(n, 1)), K, H, W // 32), dtype=torch.int32, device=dev)
+    engine.reserve(min(batch, max(n, 1)), H, W)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for a in range(0, n, batch):
+        b = min(a + batch, n)
+        engine.forward(x[a:b], logits=False, mask=True, out_mask=(masks[a:b] if keep_masks else scratch[:b - a]), stream=stream)
+    torch.cuda.synchronize(dev)
+    return lo, hi, masks, time.perf_counter() - t0

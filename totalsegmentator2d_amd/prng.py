@@ -30,6 +30,11 @@ def _key(seed: int, stream: int) -> np.uint64:
     return k[0]
 
 
+def key(seed: int, stream: int) -> int:
+    """The 64-bit stream key as a Python int (what the device generator ts2d_synth_slices takes)."""
+    return int(_key(seed, stream))
+
+
 def hash_u64(seed: int, stream: int, n: int, offset: int = 0) -> np.ndarray:
     """n 64-bit words for counters offset..offset+n-1."""
     with np.errstate(over='ignore'):
