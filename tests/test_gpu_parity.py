@@ -222,7 +222,8 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
     with Engine(arch, blob) as e:                          # default path: includes the resident-weight 32 -> 32 kernel
         lgr, _ = e.forward(x, logits=True)
         tr = {n: e.debug_tensor(n) for n in names}
-    monkeypatch.setenv('TS2D_RES', '0')                    # (conv3x3_res32 sums in another order: compared by value below)
+    monkeypatch.setenv('TS2D_RES', '0')                    # (conv3x3_res32 and conv3x3s2_v2 sum in another order: compared by value below)
+    monkeypatch.setenv('TS2D_S2V2', '0')
     with Engine(arch, blob) as e:
         lg1, _ = e.forward(x, logits=True)
         t1 = {n: e.debug_tensor(n) for n in names}
@@ -233,7 +234,8 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
     for n in names:
         assert np.array_equal(t0[n], t1[n]), n
     assert np.abs(lg0 - lg1).max() <= 1e-5
-    # conv3x3_res32 (one 288-term accumulation per output instead of two 144-term chunks): same values to fp32 rounding
+    # conv3x3_res32 (one 288-term accumulation per output instead of two 144-term chunks) and conv3x3s2_v2 (16-channel chunks,
+    # one tap per k-step): same values to fp32 rounding
     for n in names:
         assert np.abs(tr[n] - t1[n]).max() <= 2e-5, n
     assert np.abs(lgr - lg1).max() <= 2e-5

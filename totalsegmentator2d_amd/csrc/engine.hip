@@ -10,6 +10,7 @@
 #include "kernels_f16x3_one.h"
 #include "kernels_first.h"
 #include "kernels_res32.h"
+#include "kernels_s2v2.h"
 #include "kernels_sw.h"
 #include "kernels_project.h"
 
@@ -65,6 +66,9 @@ struct Op {
     size_t dev_wh32 = 0;          // offset (floats) of the fp16 weights in 32-channel chunks (precision mode f16, kernels_h32.h)
     bool h32_ok = false;
     size_t dev_ws = 0;            // offset (floats) of 1 / (power-of-two pre-scale of the split weights)
+    bool s2v2_ok = false;         // stride-2 block: 512-thread kernel of kernels_s2v2.h
+    size_t dev_w2 = 0;            // offset (floats) of its weight image [chunk16][column tile][tap][hi,lo][h][column][8 halves]
+    int bn2 = 0;                  // its column tile (128 or 64)
     bool res_ok = false;          // 32 -> 32 stride-1 block: resident-weight persistent kernel (kernels_res32.h)
     size_t dev_wres = 0;          // offset (floats) of its weight image [tap][hi,lo][g][cout][8 halves]
     bool first_direct = false;    // first conv block handled by conv3x3_first (reads the NCHW boundary tensor)
@@ -107,6 +111,8 @@ struct ts2d_engine {
     int tiled_inf = 0;            // the last predict_tiled produced an infinite aggregated logit (ts2d_engine_tiled_inf_flag)
     bool use_h32 = true;          // precision mode f16: 32-channel-chunk kernel (TS2D_H32=0 falls back to the 16-channel one)
     bool use_one = true;          // one-image-tile split kernel (TS2D_ONE=0 falls back to the generic one)
+    int dbg = 0;                  // TS2D_DBG: timing ablations (diagnostic runs only)
+    bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
     bool use_res = true;          // resident-weight kernel of the 32 -> 32 blocks (TS2D_RES=0 falls back)
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
@@ -216,6 +222,10 @@ int build_program(ts2d_engine* e) {
             const size_t recs = op.stride == 1 ? (size_t)(ct / 16) * 9 : (size_t)(ct / 8) * 5;
             op.dev_wh = wo; wo = align_up(wo + recs * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);                  // 1 / scale, read by the kernel
+            if (op.stride == 2 && ct % 16 == 0 && op.cout % 64 == 0) {
+                op.s2v2_ok = true; op.bn2 = op.cout % 128 == 0 ? 128 : 64;
+                op.dev_w2 = wo; wo = align_up(wo + (size_t)ct * 9 * op.cout, 64);
+            }
             if (op.stride == 1 && ct == 32 && op.cout == 32) {      // resident image of the 32 -> 32 block: [tap][hi,lo][g][cout][8 halves]
                 op.res_ok = true;
                 op.dev_wres = wo; wo = align_up(wo + 9 * 2 * 4 * 32 * 8 / 2, 64);
@@ -344,6 +354,13 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                             if (op.h32_ok)          // same blocks with 32 real channels per record (the hi parts only)
                                 reinterpret_cast<uint16_t*>(out + op.dev_wh32)[((((size_t)(ci / 32) * (co_n / bn) + co / bn) * 9 + tap) * bn + co % bn) * 32 + ci % 32] = hi;
                         } else {       // K packed as 8 channels x 2 taps: k = 8 * (tap & 1) + (ci % 8) of k-step tap / 2
+                            if (op.s2v2_ok) {      // [chunk16][column tile][tap][hi,lo][h = (ci % 16) / 8][column][ci % 8]
+                                const int bn2 = op.bn2;
+                                uint16_t* w2 = reinterpret_cast<uint16_t*>(out + op.dev_w2);
+                                const size_t blk = ((size_t)(ci / 16) * (co_n / bn2) + co / bn2) * (9 * 2 * 2 * bn2 * 8);
+                                w2[blk + ((((size_t)tap * 2 + 0) * 2 + (ci % 16) / 8) * bn2 + co % bn2) * 8 + ci % 8] = hi;
+                                w2[blk + ((((size_t)tap * 2 + 1) * 2 + (ci % 16) / 8) * bn2 + co % bn2) * 8 + ci % 8] = lo;
+                            }
                             const int chunk = ci / 8, cc = (tap & 1) * 8 + ci % 8, bn = co_n % 64 == 0 ? 64 : 32;
                             uint16_t* rec = d + ((((size_t)chunk * (co_n / bn) + co / bn) * 5 + tap / 2) * bn + co % bn) * 32;
                             rec[cc] = hi; rec[16 + cc] = lo;
@@ -697,7 +714,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const int taps = conv ? 9 : 1, stride = conv ? op.stride : 1;
             const TileGeom g = tile_geom(B, Ht, Wt, stride, taps);
             ConvArgs ca{};
-            ca.ksplit = 1;
+            ca.ksplit = 1; ca.dbg = e->dbg;
             ca.src0 = src.data; ca.sc0 = src.scale; ca.sh0 = src.shift; ca.C0 = src.C;
             if (op.skip >= 0) { const Tensor& sk = e->tensors[op.skip]; ca.src1 = sk.data; ca.sc1 = sk.scale; ca.sh1 = sk.shift; ca.C1 = sk.C; }
             ca.wp = wts + op.dev_w; ca.bias = wts + op.dev_b; ca.dst = dst.data;
@@ -713,6 +730,31 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const int P = (g.PH * g.PW) << g.lgNIMG;
             const bool split = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT;
             if (f16 && !split) return fail(TS2D_ERR_INVALID, "op %s has no fp16 kernel (channel counts must be multiples of 16)", op.name.c_str());
+            if (conv && split && op.s2v2_ok && e->use_s2v2 && e->use_one && stride == 2 && g.lgNIMG == 0 && Ht % 8 == 0 && Wt % 32 == 0 &&
+                ca.lg_tx >= 0 && ca.lg_tpi >= 0 && lg_exact(op.cout / op.bn2) >= 0 &&
+                (size_t)Hin * Win * op.cin * 4 < ((size_t)1 << 31) && (size_t)Ht * Wt * op.cout * 4 < ((size_t)1 << 31)) {
+                // stride-2 block on full 8 x 32 output tiles: one 512-thread workgroup per CU, up to 128 output columns
+                ca.n_ctiles = op.cout / op.bn2; ca.lg_nct = lg_exact(ca.n_ctiles);
+                ca.wph = wts + op.dev_w2; ca.oscale = wts + op.dev_ws; ca.part = e->d_part;
+                const int grid2 = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
+                const int npp = f16 ? 1 : 2;
+                const size_t smem2 = (size_t)npp * 2 * kS2Plane + (size_t)9 * npp * 2 * op.bn2 * 16;
+                TRY(prof_begin(e, op.name, st));
+#define TS2D_S2V2_LAUNCH(BN_, ST_, NP_) do { static std::atomic<uint64_t> done_{0}; \
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_>), done_)); \
+                    hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } while (0)
+                if (op.bn2 == 128) { if (f16) TS2D_S2V2_LAUNCH(128, _Float16, 1); else TS2D_S2V2_LAUNCH(128, float, 3); }
+                else { if (f16) TS2D_S2V2_LAUNCH(64, _Float16, 1); else TS2D_S2V2_LAUNCH(64, float, 3); }
+#undef TS2D_S2V2_LAUNCH
+                HIP_TRY(hipGetLastError());
+                TRY(prof_end(e, st));
+                TRY(prof_begin(e, op.name + ".stats", st));
+                hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
+                                   op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+                HIP_TRY(hipGetLastError());
+                TRY(prof_end(e, st));
+                continue;
+            }
             if (conv && split && op.res_ok && e->use_res && e->use_one && src.scale != nullptr && op.skip < 0 && Ht % 8 == 0 && Wt % 32 == 0 &&
                 (size_t)Ht * Wt * 32 * 4 < ((size_t)1 << 31)) {
                 // 32 -> 32 stride-1 block on full 8 x 32 tiles: persistent kernel with the layer's weights resident in LDS
@@ -880,6 +922,8 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_H32")) e->use_h32 = getenv("TS2D_H32")[0] == '1';
         if (getenv("TS2D_ONE")) e->use_one = getenv("TS2D_ONE")[0] == '1';
         if (getenv("TS2D_RES")) e->use_res = getenv("TS2D_RES")[0] == '1';
+        if (getenv("TS2D_S2V2")) e->use_s2v2 = getenv("TS2D_S2V2")[0] == '1';
+        if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
     }
     int rc = build_program(e);
     if (rc != TS2D_OK) { delete e; return rc; }

@@ -44,6 +44,8 @@ struct ConvArgs {
     const void* wph;      // split-fp16 packed weights [chunk][tap][N][16 hi | 16 lo] (f16x3 kernel only)
     int ksplit;           // split-K: blockIdx.y = K slice; slice s writes un-biased partials to dst + s * kslice_stride
     long long kslice_stride;
+    int dbg;              // timing ablations of diagnostic runs (TS2D_DBG; 0 in production): bit 0 = skip the MFMA phase, bit 1 = skip the
+                          // patch conversion, bit 2 = skip the weight staging
     const float* oscale;  // device scalar: 1 / (power-of-two weight pre-scale); lives in the weight arena so that it
                           // travels with the multi-GPU weight broadcast (f16x3 kernel only)
 };
