@@ -99,6 +99,15 @@ int ts2d_engine_weights_ready(ts2d_engine* e);
 int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W, float* logits,
                         uint32_t* mask_packed, int on_device, void* stream);
 
+/* Result check of the LAST forward / predict_tiled (synchronises it): TS2D_OK, or TS2D_ERR_INVALID when a logit came out inf / NaN,
+ * with ts2d_last_error() naming the first layer (program order) whose output holds a non-finite value.  The split and f16 modes
+ * multiply fp16 operands: an activation of magnitude >= 65504 at a conv input (impossible after InstanceNorm for |gamma| < 127,
+ * possible for an un-normalised transposed-conv output with adversarial weights) overflows to inf - this check turns that into an
+ * error instead of a silent inf; TS2D_PRECISION_F32_EXACT has no such limit.  Host-buffer forwards and ts2d_engine_predict_tiled
+ * run it themselves; after an asynchronous device-pointer forward the caller may.  (Reference convention: a failing prediction
+ * raises, ts2d/core/inference/prediction_worker.py:211-212; upstream nnU-Net only checks the aggregated array for inf.) */
+int ts2d_engine_check(ts2d_engine* e);
+
 /* Sliding-window inference of ONE preprocessed 2-D image on the device (replaces the body of nnU-Net's
  * predict_sliding_window_return_logits + _internal_maybe_mirror_and_predict for one fold: reference call site
  * ts2d/core/inference/prediction_worker.py:209; SURVEY.md rows A3-A5, and A7 for `seg`).

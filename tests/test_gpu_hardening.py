@@ -1,0 +1,72 @@
+"""The split mode (fp16 hi/lo products) under adversarial weights: large InstanceNorm gains, weights spanning 20 binades inside
+one layer, and an un-normalised transposed-conv output driven past the fp16 range - which must surface as an error naming the
+layer, never as a silent inf."""
+import numpy as np
+import pytest
+
+from tests import cases
+from totalsegmentator2d_amd import weights
+from totalsegmentator2d_amd.engine import Engine
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case():
+    arch = cases.unet(4, (32, 64, 128, 128), 5)
+    sd = weights.synthetic_state_dict(arch, 61)
+    x = cases.make_input(arch, 2, 64, 64, 61)
+    return arch, sd, x
+
+
+def _rel_err(lg, ref):
+    return float(np.abs(lg - ref).max() / max(1.0, float(np.abs(ref).max())))
+
+
+def test_large_instance_norm_gains():
+    arch, sd, x = _case()
+    sd = {k: (v * np.float32(100.0) if k.endswith('norm.weight') else v) for k, v in sd.items()}      # |gamma| ~ 100
+    ref = O.unet_forward(arch, sd, x).numpy()
+    with Engine(arch, weights.pack_blob(arch, sd)) as e:
+        lg, _ = e.forward(x)
+    assert np.isfinite(lg).all() and _rel_err(lg, ref) <= 1e-4
+
+
+def test_weights_spanning_twenty_binades_in_one_layer():
+    arch, sd, x = _case()
+    rng = np.random.default_rng(0)
+    sd = dict(sd)
+    for k in list(sd):
+        if k.endswith('conv.weight') and sd[k].ndim == 4 and sd[k].shape[1] >= 32:
+            w = sd[k].copy()
+            scale = np.exp2(-rng.integers(0, 21, size=w.shape)).astype(np.float32)      # 2^0 .. 2^-20, element by element
+            sd[k] = w * scale        # the per-layer power-of-two pre-scale is set by the largest weight: small ones lose their lo part
+    ref = O.unet_forward(arch, sd, x).numpy()
+    with Engine(arch, weights.pack_blob(arch, sd)) as e:
+        lg, _ = e.forward(x)
+    assert np.isfinite(lg).all() and _rel_err(lg, ref) <= 1e-4
+
+
+def test_overflowing_transposed_conv_output_is_an_error_naming_the_layer():
+    arch, sd, x = _case()
+    blob_ok = weights.pack_blob(arch, sd)
+    sd = dict(sd)
+    key = 'decoder.transpconvs.1.weight'
+    sd[key] = sd[key] * np.float32(3e5)                    # un-normalised output of dec1.up far beyond 65504
+    blob = weights.pack_blob(arch, sd)
+    with Engine(arch, blob) as e:
+        with pytest.raises(RuntimeError, match=r'non-finite logits: inf / NaN first appears in layer dec1\.c0'):
+            e.forward(x)                                   # host-buffer forward runs ts2d_engine_check itself
+        import torch
+        e.forward(torch.from_numpy(x).cuda())              # asynchronous device-pointer call: no error yet ...
+        with pytest.raises(RuntimeError, match='non-finite'):
+            e.check()                                      # ... until the caller asks
+        e.set_precision('exact')                           # the fp32 MFMA path has no fp16 range limit
+        lg, _ = e.forward(x)
+        assert np.isfinite(lg).all()
+        ref = O.unet_forward(arch, sd, x).numpy()
+        assert _rel_err(lg, ref) <= 1e-4
+        e.set_precision('split')
+        e.load_weights(blob_ok)                            # the flag does not stick: sane weights, same engine
+        good, _ = e.forward(x)
+        assert np.isfinite(good).all()

@@ -20,7 +20,7 @@ PRECISION_F16 = 2
 
 # every symbol include/ts2d_engine.h declares
 SYMBOLS = ('ts2d_engine_create', 'ts2d_engine_load_weights', 'ts2d_engine_weight_buffer', 'ts2d_engine_weights_ready',
-           'ts2d_engine_forward', 'ts2d_engine_predict_tiled', 'ts2d_engine_tiled_inf_flag', 'ts2d_engine_set_tile_dtype', 'ts2d_project_coronal', 'ts2d_synth_slices', 'ts2d_engine_reserve', 'ts2d_engine_set_precision', 'ts2d_engine_set_profiling', 'ts2d_engine_num_ops',
+           'ts2d_engine_forward', 'ts2d_engine_check', 'ts2d_engine_predict_tiled', 'ts2d_engine_tiled_inf_flag', 'ts2d_engine_set_tile_dtype', 'ts2d_project_coronal', 'ts2d_synth_slices', 'ts2d_engine_reserve', 'ts2d_engine_set_precision', 'ts2d_engine_set_profiling', 'ts2d_engine_num_ops',
            'ts2d_engine_op_name', 'ts2d_engine_op_times', 'ts2d_engine_debug_tensor', 'ts2d_engine_device_bytes', 'ts2d_engine_destroy',
            'ts2d_last_error', 'ts2d_abi_version')
 
@@ -77,6 +77,8 @@ def load():
     lib.ts2d_engine_forward.restype = c.c_int
     lib.ts2d_engine_forward.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_void_p,
                                         c.c_int, c.c_void_p]
+    lib.ts2d_engine_check.restype = c.c_int
+    lib.ts2d_engine_check.argtypes = [c.c_void_p]
     lib.ts2d_engine_predict_tiled.restype = c.c_int
     lib.ts2d_engine_predict_tiled.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_void_p,
                                               c.c_int, c.c_void_p, c.c_void_p, c.c_void_p]

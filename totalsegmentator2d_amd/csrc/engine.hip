@@ -127,6 +127,8 @@ struct ts2d_engine {
     // The activation workspace is shared by every call on this handle, whatever stream the caller passes: the end of each run
     // is marked with an event, and a run issued on ANOTHER stream first waits for it (no host synchronisation).
     hipEvent_t ws_event = nullptr; hipStream_t ws_stream = nullptr; bool ws_busy = false;
+    int* d_flags = nullptr;       // [0]: a logit of the last run was inf / NaN (set by the head kernels); [1]: scratch of the diagnosis
+    bool checked_input = false; const float* last_input = nullptr;      // (synchronous paths: the staged input can be scanned too)
 };
 
 namespace {
@@ -659,6 +661,9 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
 int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st) {
     const ts2d_arch_desc& a = e->arch;
     e->n_launched = 0;
+    // (the input is scanned by ts2d_engine_check only when it lives in the engine's own staging memory)
+    e->last_input = (d_in == e->d_in_stage || (e->d_sw && reinterpret_cast<const char*>(d_in) >= e->d_sw &&
+                                               reinterpret_cast<const char*>(d_in) < e->d_sw + e->sw_bytes)) ? d_in : nullptr;
     e->lastB = B; e->lastH = H; e->lastW = W; e->last_stream = st;
     const bool f16 = e->precision == TS2D_PRECISION_F16;      // fp16 storage, one fp16 MFMA product, fp32 accumulate/statistics
     e->last_f16 = f16;
@@ -866,7 +871,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             HeadArgs ha{};
             ha.src = src.data; ha.sc = src.scale; ha.sh = src.shift; ha.w = wts + op.dev_w; ha.bias = wts + op.dev_b;
             ha.logits = d_logits; ha.mask = d_mask; ha.C = src.C; ha.K = op.cout; ha.HW = H * W;
-            ha.total = (long long)B * H * W; ha.slope = a.leaky_slope;
+            ha.total = (long long)B * H * W; ha.slope = a.leaky_slope; ha.nonfinite = e->d_flags;
             const unsigned grid = (unsigned)((ha.total + 255) / 256);
             const size_t smem = ((size_t)256 * (src.C + 1) + (size_t)op.cout * src.C + op.cout) * sizeof(float);
             TRY(prof_begin(e, op.name, st));
@@ -930,6 +935,8 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
     hipError_t he = hipSetDevice(device);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ws_event, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&e->d_flags), 2 * sizeof(int));
+    if (he == hipSuccess) he = hipMemset(e->d_flags, 0, 2 * sizeof(int));
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&e->d_weights), e->weight_floats * sizeof(float));
     if (he != hipSuccess) {
         rc = fail(he == hipErrorOutOfMemory ? TS2D_ERR_NOMEM : TS2D_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he));
@@ -1000,6 +1007,7 @@ int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W,
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
     const int K = e->arch.num_classes;
+    HIP_TRY(hipMemsetAsync(e->d_flags, 0, 2 * sizeof(int), st));
     if (on_device) return run_forward(e, input, B, H, W, logits, mask_packed, st);
     // host buffers: staged through the workspace, synchronous
     HIP_TRY(hipMemcpyAsync(e->d_in_stage, input, (size_t)B * e->arch.input_channels * H * W * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1007,7 +1015,7 @@ int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W,
     if (logits) HIP_TRY(hipMemcpyAsync(logits, e->d_logit_stage, (size_t)B * K * H * W * sizeof(float), hipMemcpyDeviceToHost, st));
     if (mask_packed) HIP_TRY(hipMemcpyAsync(mask_packed, e->d_mask_stage, (size_t)B * K * H * (W / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    return TS2D_OK;
+    return ts2d_engine_check(e);          // never a silent inf / NaN (asynchronous device-pointer calls: the caller runs the check)
 }
 
 int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp, int ph, int pw, int n_tiles,
@@ -1052,6 +1060,7 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
     HIP_TRY(hipMemcpyAsync(d_tx, tile_x, (size_t)n_tiles * 4, hipMemcpyHostToDevice, st));
     int* d_flag = reinterpret_cast<int*>(b + o_flag);
     HIP_TRY(hipMemsetAsync(d_flag, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(e->d_flags, 0, 2 * sizeof(int), st));
     HIP_TRY(hipMemcpyAsync(d_vf, vflip, 16, hipMemcpyHostToDevice, st));
     if (gaussian_f16) HIP_TRY(hipMemcpyAsync(d_g, gaussian_f16, (size_t)ph * pw * 2, hipMemcpyHostToDevice, st));
     {
@@ -1075,7 +1084,43 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
     if (logits_f16) HIP_TRY(hipMemcpyAsync(logits_f16, d_o16, (size_t)K * Hp * Wp * 2, hipMemcpyDeviceToHost, st));
     if (seg_u8) HIP_TRY(hipMemcpyAsync(seg_u8, d_seg, (size_t)K * Hp * Wp, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    return TS2D_OK;
+    return ts2d_engine_check(e);
+}
+
+int ts2d_engine_check(ts2d_engine* e) {
+    if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_check: null engine");
+    if (!e->lastB) return TS2D_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->ws_busy) HIP_TRY(hipEventSynchronize(e->ws_event));
+    int flags[2] = {0, 0};
+    HIP_TRY(hipMemcpy(flags, e->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+    if (!flags[0]) return TS2D_OK;
+    // Diagnosis (slow path, the activations of the run are still resident): the first tensor in program order that holds inf / NaN.
+    auto has_nonfinite = [&](const void* p, size_t n, bool half) -> int {
+        if (hipMemset(e->d_flags + 1, 0, sizeof(int)) != hipSuccess) return -1;
+        const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+        if (half) hipLaunchKernelGGL(scan_nonfinite<_Float16>, dim3(grid), dim3(256), 0, 0, reinterpret_cast<const _Float16*>(p), n, e->d_flags + 1);
+        else hipLaunchKernelGGL(scan_nonfinite<float>, dim3(grid), dim3(256), 0, 0, reinterpret_cast<const float*>(p), n, e->d_flags + 1);
+        int f = 0;
+        if (hipMemcpy(&f, e->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return f;
+    };
+    const int B = e->lastB, H = e->lastH, W = e->lastW;
+    std::string where = "head";
+    if (e->last_input && has_nonfinite(e->last_input, (size_t)B * e->arch.input_channels * H * W, false) == 1) where = "the network input";
+    else
+        for (const Op& op : e->ops) {
+            if (op.dst < 0) continue;
+            const Tensor& t = e->tensors[op.dst];
+            const size_t n = (size_t)B * (H >> t.level) * (W >> t.level) * t.C;
+            const int f = has_nonfinite(t.data, n, e->last_f16);
+            const int g = (f == 0 && t.normed) ? has_nonfinite(t.scale, (size_t)B * t.C, false) : 0;
+            if (f == 1 || g == 1) { where = "layer " + op.name + (f == 1 ? "" : " (InstanceNorm statistics)"); break; }
+        }
+    return fail(TS2D_ERR_INVALID, "non-finite logits: inf / NaN first appears in %s%s", where.c_str(),
+                e->precision == TS2D_PRECISION_F32_EXACT ? "" :
+                " (the fp16 products of this precision mode need |activation| < 65504 at every conv input: "
+                "an overflowing activation - e.g. an un-normalised transposed-conv output - becomes inf; use TS2D_PRECISION_F32_EXACT for such weights)");
 }
 
 int ts2d_engine_tiled_inf_flag(const ts2d_engine* e) { return e ? (e->tiled_inf != 0) : 0; }
@@ -1199,6 +1244,7 @@ int ts2d_engine_destroy(ts2d_engine* e) {
     if (e->ws_event) (void)hipEventDestroy(e->ws_event);
     for (Launch& l : e->launches) { if (l.e0) (void)hipEventDestroy(l.e0); if (l.e1) (void)hipEventDestroy(l.e1); }
     if (e->d_ws) (void)hipFree(e->d_ws);
+    if (e->d_flags) (void)hipFree(e->d_flags);
     if (e->d_sw) (void)hipFree(e->d_sw);
     if (e->d_weights) (void)hipFree(e->d_weights);
     if (e->stream) (void)hipStreamDestroy(e->stream);

@@ -391,7 +391,19 @@ struct HeadArgs {
     float* logits; uint32_t* mask;                         // NCHW [B,K,H,W]; [B,K,H,W/32] (either may be nullptr)
     int C, K, HW; long long total;                         // total = B*H*W pixels
     float slope;
+    int* nonfinite;                                        // device flag, set when a logit is inf / NaN (ts2d_engine_check)
 };
+
+// true for +-inf and NaN
+__device__ __forceinline__ bool not_finite(float v) { return !(__builtin_fabsf(v) < __builtin_inff()); }
+
+// Diagnosis pass of ts2d_engine_check: does a tensor hold a non-finite value?  (run only after the head reported one)
+template <typename ST>
+__global__ void scan_nonfinite(const ST* __restrict__ p, size_t n, int* __restrict__ flag) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) bad |= not_finite((float)p[i]);
+    if (bad) atomicOr(flag, 1);
+}
 
 template <int C, typename ST = float>
 __global__ __launch_bounds__(256) void head_1x1(const HeadArgs a) {
@@ -433,11 +445,13 @@ __global__ __launch_bounds__(256) void head_1x1(const HeadArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c) xr[c] = sx[tid * (C + 1) + c];
     const long long n = valid ? p / a.HW : 0, o = valid ? p - n * a.HW : 0;
+    bool bad = false;
     for (int k = 0; k < a.K; ++k) {
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) acc = fmaf(xr[c], sw[k * C + c], acc);
         acc += sw[a.K * C + k];
+        if (valid && not_finite(acc)) bad = true;
         if (a.logits != nullptr && valid) a.logits[(n * a.K + k) * a.HW + o] = acc;
         if (a.mask != nullptr) {
             const unsigned long long bits = __ballot(valid && acc > kSigmoidHalfThreshold);
@@ -446,6 +460,7 @@ __global__ __launch_bounds__(256) void head_1x1(const HeadArgs a) {
                 *reinterpret_cast<unsigned long long*>(a.mask + ((n * a.K + k) * a.HW + o) / 32) = bits;
         }
     }
+    if (bad && a.nonfinite != nullptr) atomicOr(a.nonfinite, 1);
 }
 
 }  // namespace ts2d

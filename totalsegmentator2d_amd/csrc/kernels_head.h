@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void head_mfma32(const HeadArgs a, const int b
             raw[l] = *reinterpret_cast<const uint4*>(p + (sizeof(ST) == 4 ? (l >> 1) * 16 + (l & 1) * 4 : l * 16));
     };
     prefetch(b0);
+    bool bad = false;
     for (long long b = b0; b < b1; ++b) {
         uint4 x[NL];
 #pragma unroll
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void head_mfma32(const HeadArgs a, const int b
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[e] = acc[4 * q + e] * oscale + bv;
+                bad |= not_finite(v[e]);
                 bits |= (v[e] > kSigmoidHalfThreshold ? 1u : 0u) << (e + 8 * q + 4 * h);
             }
             if (lp != nullptr && r < a.K) *reinterpret_cast<f32x4*>(lp + 8 * q) = v;
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256) void head_mfma32(const HeadArgs a, const int b
         o += 32;
         if (o == a.HW) { o = 0; ++n; if (b + 1 < b1) load_st(); }
     }
+    if (bad && r < a.K && a.nonfinite != nullptr) atomicOr(a.nonfinite, 1);
 }
 
 }  // namespace ts2d

@@ -150,6 +150,11 @@ class Engine:
             out_mask.ctypes.data if mask else None, 0, None), 'ts2d_engine_forward')
         return (out_logits if logits else None), (out_mask if mask else None)
 
+    def check(self):
+        """Synchronise the last forward and raise RuntimeError if it produced inf / NaN logits, naming the first layer whose
+        output is non-finite (C-ABI ts2d_engine_check).  numpy forwards and predict_tiled run it themselves."""
+        _lib.check(self.lib.ts2d_engine_check(self._h), 'ts2d_engine_check')
+
     def predict_tiled(self, image: np.ndarray, patch, tiles, mirror_axes=None, gaussian: Optional[np.ndarray] = None,
                       want_logits: bool = True, want_seg: bool = False, out_logits: Optional[np.ndarray] = None):
         """Device-side sliding window for one padded 2-D image [C,Hp,Wp] (C-ABI ts2d_engine_predict_tiled).
