@@ -11,6 +11,7 @@
 #include "kernels_first.h"
 #include "kernels_res32.h"
 #include "kernels_s2v2.h"
+#include "kernels_wino.h"
 #include "kernels_sw.h"
 #include "kernels_project.h"
 
@@ -66,6 +67,9 @@ struct Op {
     size_t dev_wh32 = 0;          // offset (floats) of the fp16 weights in 32-channel chunks (precision mode f16, kernels_h32.h)
     bool h32_ok = false;
     size_t dev_ws = 0;            // offset (floats) of 1 / (power-of-two pre-scale of the split weights)
+    bool wino_ok = false;         // stride-1 block eligible for the Winograd F(2x2,3x3) kernel (kernels_wino.h)
+    size_t dev_wu = 0;            // offset (floats) of U = G g G^T, split fp16: [chunk16][column tile 64][position 16][hi,lo][h][column][8 halves]
+    size_t dev_wus = 0;           // offset (floats) of 1 / (power-of-two pre-scale of U)
     bool s2v2_ok = false;         // stride-2 block: 512-thread kernel of kernels_s2v2.h
     size_t dev_w2 = 0;            // offset (floats) of its weight image [chunk16][column tile][tap][hi,lo][h][column][8 halves]
     int bn2 = 0;                  // its column tile (128 or 64)
@@ -112,6 +116,7 @@ struct ts2d_engine {
     bool use_h32 = true;          // precision mode f16: 32-channel-chunk kernel (TS2D_H32=0 falls back to the 16-channel one)
     bool use_one = true;          // one-image-tile split kernel (TS2D_ONE=0 falls back to the generic one)
     int dbg = 0;                  // TS2D_DBG: timing ablations (diagnostic runs only)
+    int wino_min = 0;             // Winograd kernel for stride-1 blocks with at least this many input channels (TS2D_WINO; 0 = off)
     bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
     bool use_res = true;          // resident-weight kernel of the 32 -> 32 blocks (TS2D_RES=0 falls back)
     // workspace
@@ -224,6 +229,11 @@ int build_program(ts2d_engine* e) {
             const size_t recs = op.stride == 1 ? (size_t)(ct / 16) * 9 : (size_t)(ct / 8) * 5;
             op.dev_wh = wo; wo = align_up(wo + recs * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);                  // 1 / scale, read by the kernel
+            if (op.stride == 1 && ct % 16 == 0 && op.cout % 64 == 0 && op.cin % 16 == 0 && op.cin_skip % 16 == 0) {
+                op.wino_ok = true;
+                op.dev_wu = wo; wo = align_up(wo + (size_t)ct * op.cout * 16, 64);
+                op.dev_wus = wo; wo = align_up(wo + 1, 64);
+            }
             if (op.stride == 2 && ct % 16 == 0 && op.cout % 64 == 0) {
                 op.s2v2_ok = true; op.bn2 = op.cout % 128 == 0 ? 128 : 64;
                 op.dev_w2 = wo; wo = align_up(wo + (size_t)ct * 9 * op.cout, 64);
@@ -372,6 +382,42 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
         }
     }
     for (const Op& op : e->ops) {
+        if (!op.wino_ok) continue;
+        // Winograd filter transform U = G g G^T in fp64 (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), then the usual power-of-two
+        // pre-scale and fp16 hi/lo split; one contiguous 64-KB block per (chunk of 16 input channels, tile of 64 output channels).
+        const int ct = op.cin + op.cin_skip, co_n = op.cout;
+        const float* w = blob + op.blob_w;
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        std::vector<double> U((size_t)co_n * ct * 16);
+        double mx = 0.0;
+        for (int co = 0; co < co_n; ++co)
+            for (int ci = 0; ci < ct; ++ci) {
+                const float* g = w + ((size_t)co * ct + ci) * 9;
+                double t[4][3];
+                for (int i = 0; i < 4; ++i)
+                    for (int b = 0; b < 3; ++b) t[i][b] = G[i][0] * g[0 * 3 + b] + G[i][1] * g[1 * 3 + b] + G[i][2] * g[2 * 3 + b];
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) {
+                        const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                        U[((size_t)co * ct + ci) * 16 + i * 4 + j] = u;
+                        mx = std::max(mx, std::fabs(u));
+                    }
+            }
+        const float wscale = (mx > 0.0 && std::isfinite(mx)) ? std::exp2(std::floor(std::log2(16383.0 / mx))) : 1.f;
+        out[op.dev_wus] = 1.0f / wscale;
+        uint16_t* d = reinterpret_cast<uint16_t*>(out + op.dev_wu);
+        for (int co = 0; co < co_n; ++co)
+            for (int ci = 0; ci < ct; ++ci)
+                for (int xi = 0; xi < 16; ++xi) {
+                    const float v = (float)(U[((size_t)co * ct + ci) * 16 + xi] * (double)wscale);
+                    const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                    const size_t blk = ((size_t)(ci / 16) * (co_n / 64) + co / 64) * (16 * 2 * 2 * 64 * 8);
+                    const int hh = (ci % 16) / 8, e8 = ci % 8, col = co % 64;
+                    d[blk + ((((size_t)xi * 2 + 0) * 2 + hh) * 64 + col) * 8 + e8] = hi;
+                    d[blk + ((((size_t)xi * 2 + 1) * 2 + hh) * 64 + col) * 8 + e8] = lo;
+                }
+    }
+    for (const Op& op : e->ops) {
         const int ct = op.cin + op.cin_skip, co_n = op.cout;
         if (op.type == OP_CONV) {           // W[co][ci][ky][kx] -> [chunk][tap][kk][co][8]
             const int ck = op.ck, kkn = ck / 8;
@@ -414,6 +460,8 @@ int upload_weights(ts2d_engine* e, const float* blob, size_t n_floats) {
     e->weights_ready = true;
     return TS2D_OK;
 }
+
+inline int ct_total(const Op& op) { return op.cin + op.cin_skip; }
 
 struct TileGeom { int lgTH, lgTW, lgNIMG, tiles_x, tiles_y, n_mtiles, PH, PW; };
 
@@ -735,6 +783,28 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const int P = (g.PH * g.PW) << g.lgNIMG;
             const bool split = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT;
             if (f16 && !split) return fail(TS2D_ERR_INVALID, "op %s has no fp16 kernel (channel counts must be multiples of 16)", op.name.c_str());
+            if (conv && split && !f16 && op.wino_ok && e->wino_min > 0 && ct_total(op) >= e->wino_min && e->use_one && stride == 1 && g.lgNIMG == 0 &&
+                Ht % 8 == 0 && Wt % 32 == 0 && ca.lg_tx >= 0 && ca.lg_tpi >= 0 && lg_exact(op.cout / 64) >= 0 &&
+                (size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4 < ((size_t)1 << 31) && (size_t)Ht * Wt * op.cout * 4 < ((size_t)1 << 31)) {
+                // stride-1 block on full 8 x 32 tiles: Winograd F(2x2,3x3), one 512-thread workgroup per CU, 64 output columns
+                ca.n_ctiles = op.cout / 64; ca.lg_nct = lg_exact(ca.n_ctiles);
+                ca.wph = wts + op.dev_wu; ca.oscale = wts + op.dev_wus; ca.part = e->d_part;
+                const int gridw = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
+                TRY(prof_begin(e, op.name, st));
+                {
+                    static std::atomic<uint64_t> donew{0};
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_wino), donew));
+                    hipLaunchKernelGGL(conv3x3_wino, dim3(gridw), dim3(kWThreads), kWLds, st, ca);
+                }
+                HIP_TRY(hipGetLastError());
+                TRY(prof_end(e, st));
+                TRY(prof_begin(e, op.name + ".stats", st));
+                hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
+                                   op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+                HIP_TRY(hipGetLastError());
+                TRY(prof_end(e, st));
+                continue;
+            }
             if (conv && split && op.s2v2_ok && e->use_s2v2 && e->use_one && stride == 2 && g.lgNIMG == 0 && Ht % 8 == 0 && Wt % 32 == 0 &&
                 ca.lg_tx >= 0 && ca.lg_tpi >= 0 && lg_exact(op.cout / op.bn2) >= 0 &&
                 (size_t)Hin * Win * op.cin * 4 < ((size_t)1 << 31) && (size_t)Ht * Wt * op.cout * 4 < ((size_t)1 << 31)) {
@@ -929,6 +999,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_RES")) e->use_res = getenv("TS2D_RES")[0] == '1';
         if (getenv("TS2D_S2V2")) e->use_s2v2 = getenv("TS2D_S2V2")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
+        if (getenv("TS2D_WINO")) e->wino_min = atoi(getenv("TS2D_WINO"));
     }
     int rc = build_program(e);
     if (rc != TS2D_OK) { delete e; return rc; }
