@@ -163,6 +163,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='slices per GPU per step (config 2: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
+    ap.add_argument('--no-other-modes', action='store_true', help='skip the exact / f16 legs (profiling runs: only the timed mode launches kernels)')
     ap.add_argument('--workload', choices=('config2', 'config3', 'config4'), default='config2')
     ap.add_argument('--stream', type=int, default=None, help='config 4: total slices of the synthetic stream (default 10000)')
     ap.add_argument('--precision', choices=('split', 'exact', 'f16'), default=None,
@@ -343,7 +344,7 @@ def main():
                                'whole_step_fp32_mfma_equiv_frac': round(value / world * work['flops'] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
             top = sorted(op_ms.items(), key=lambda kv: -kv[1])[:8]
             out['top_ops_ms'] = {k: round(v / args.steps, 3) for k, v in top}
-        if world == 1:
+        if world == 1 and not args.no_other_modes:
             # the other arithmetic mode on the same workload (outside the timed region above; same step definition)
             other = 'exact' if split else 'split'
             out['f16_mode'] = None

@@ -789,6 +789,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 // stride-1 block on full 8 x 32 tiles: Winograd F(2x2,3x3), one 512-thread workgroup per CU, 64 output columns
                 ca.n_ctiles = op.cout / 64; ca.lg_nct = lg_exact(ca.n_ctiles);
                 ca.wph = wts + op.dev_wu; ca.oscale = wts + op.dev_wus; ca.part = e->d_part;
+                // (grid: 8 XCD lanes x enough rows for either block map of the kernel; surplus blocks return at once)
                 const int gridw = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
                 TRY(prof_begin(e, op.name, st));
                 {

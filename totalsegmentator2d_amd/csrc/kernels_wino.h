@@ -35,11 +35,16 @@ __global__ __launch_bounds__(kWThreads, 2) void conv3x3_wino(const ConvArgs a) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+    // ---- block -> (pixel tile, column tile).  Blocks b and b + 8 share an XCD and its L2.  The per-chunk operand that every
+    //      workgroup re-reads is the 64-KB weight block U(chunk, column tile) - larger than the 22-KB activation patch - so the
+    //      blocks of one XCD work on the SAME column tile (different pixel tiles): an XCD streams 1/8 of the layer's U through
+    //      its L2 instead of all of it.  (a.dbg & 16: the pixel-tile-major map of the direct kernels, for comparison.)
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = bid >> 3;
-    const int qm = q8 >> a.lg_nct;                         // (power-of-two tilings only: the engine checks)
-    const int mtile = qm * 8 + xcd;
-    const int ctile = q8 - qm * a.n_ctiles;
+    int mtile, ctile;
+    if (a.dbg & 16) { const int qm = q8 >> a.lg_nct; mtile = qm * 8 + xcd; ctile = q8 - qm * a.n_ctiles; }
+    else if (a.n_ctiles >= 8) { const int per = a.n_ctiles >> 3; ctile = xcd + 8 * (q8 & (per - 1)); mtile = q8 >> (a.lg_nct - 3); }
+    else { const int rep = 8 >> a.lg_nct; ctile = xcd & (a.n_ctiles - 1); mtile = q8 * rep + (xcd >> a.lg_nct); }
     if (mtile >= a.n_mtiles) return;
     const int n0col = ctile * 64;
     const int tpi = a.tiles_x * a.tiles_y;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(kWThreads, 2) void conv3x3_wino(const ConvArgs a) {
             }
 #pragma unroll
             for (int it = 0; it < NU1; ++it) {
-                if (vo0[it] != 0x80000000u) {
+                if (vo0[it] != 0x80000000u && !(a.dbg & 8)) {
                     f32x4 v = __builtin_bit_cast(f32x4, pv[it]);
                     if (normed) {
                         v = v * ns + nt4;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(kWThreads, 2) void conv3x3_wino(const ConvArgs a) {
         }
         __syncthreads();                                   // R complete; every wave is done with the previous chunk's V and U
         // ---- stage 2: V = B^T d B of this thread's tile and channel pair, split hi / lo, written k-group major
-        {
+        if (!(a.dbg & 2)) {
             f32x2 d[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -175,15 +180,18 @@ __global__ __launch_bounds__(kWThreads, 2) void conv3x3_wino(const ConvArgs a) {
                     *reinterpret_cast<unsigned*>(smem8 + vbase + (xi * 2 + 1) * 2 * kWVplane) = lo;
                 }
         }
+        if (!(a.dbg & 4)) {
         *reinterpret_cast<uint4*>(sU + (tid) * 16) = w0;          *reinterpret_cast<uint4*>(sU + (tid + 512) * 16) = w1;
         *reinterpret_cast<uint4*>(sU + (tid + 1024) * 16) = w2;   *reinterpret_cast<uint4*>(sU + (tid + 1536) * 16) = w3;
         *reinterpret_cast<uint4*>(sU + (tid + 2048) * 16) = w4;   *reinterpret_cast<uint4*>(sU + (tid + 2560) * 16) = w5;
         *reinterpret_cast<uint4*>(sU + (tid + 3072) * 16) = w6;   *reinterpret_cast<uint4*>(sU + (tid + 3584) * 16) = w7;
+        }
         __syncthreads();                                   // V and U complete
         if (ch + 1 < nchunks) prefetch(ch + 1);            // HBM latency hides behind the MFMA phase
 
         // ---- 2 positions x (2 x 2 tiles of 32x32x16) x 3 products
         __builtin_amdgcn_s_setprio(1);
+        if (!(a.dbg & 1)) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             half8 fa[2][2], fb[2][2];                      // [block][hi, lo]
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(kWThreads, 2) void conv3x3_wino(const ConvArgs a) {
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[p][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], acc[p][mt][nt], 0, 0, 0);
+        }
         }
         __builtin_amdgcn_s_setprio(0);
     }
