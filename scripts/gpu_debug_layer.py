@@ -15,11 +15,12 @@ x = cases.make_input(arch, 2, H, W, 5)
 y, inter = O.unet_forward(arch, sd, x, return_intermediates=True)
 with Engine(arch, blob) as e:
     e.set_precision(mode)
-    lg, _ = e.forward(x)
+    import torch
+    lgt, _ = e.forward(torch.from_numpy(x).cuda()); torch.cuda.synchronize(); lg = lgt.cpu().numpy()      # (device path: no automatic finite check)
     for name in ('enc0.c0', 'enc0.c1', 'enc1.c0', 'enc1.c1', 'dec0.up', 'dec0.c0', 'dec0.c1'):
         t = e.debug_tensor(name)
         r = inter[name].numpy()
-        d = np.abs(t - r)
+        d = np.abs(np.nan_to_num(t, nan=1e9, posinf=1e9, neginf=1e9) - r)
         print(f'{name:8s} max err {d.max():.3e}  mean {d.mean():.3e}', end='')
         if d.max() > 1e-3:
             bad = np.argwhere(d > 1e-3)

@@ -8,6 +8,7 @@
 #include "kernels_h32.h"
 #include "kernels_head.h"
 #include "kernels_f16x3_one.h"
+#include "kernels_f16x3_p.h"
 #include "kernels_first.h"
 #include "kernels_res32.h"
 #include "kernels_s2v2.h"
@@ -67,6 +68,8 @@ struct Op {
     size_t dev_wh32 = 0;          // offset (floats) of the fp16 weights in 32-channel chunks (precision mode f16, kernels_h32.h)
     bool h32_ok = false;
     size_t dev_ws = 0;            // offset (floats) of 1 / (power-of-two pre-scale of the split weights)
+    size_t dev_wp = 0;            // offset (floats) of the split-fp16 weights in plane order [chunk16][column tile][tap][hi,lo][h][column][8 halves]
+                                  // (conv3x3_f16x3_p; stride-1 split_ok convs)
     bool wino_ok = false;         // stride-1 block eligible for the Winograd F(2x2,3x3) kernel (kernels_wino.h)
     size_t dev_wu = 0;            // offset (floats) of U = G g G^T, split fp16: [chunk16][column tile 64][position 16][hi,lo][h][column][8 halves]
     size_t dev_wus = 0;           // offset (floats) of 1 / (power-of-two pre-scale of U)
@@ -117,6 +120,7 @@ struct ts2d_engine {
     bool use_one = true;          // one-image-tile split kernel (TS2D_ONE=0 falls back to the generic one)
     int dbg = 0;                  // TS2D_DBG: timing ablations (diagnostic runs only)
     int wino_min = 0;             // Winograd kernel for stride-1 blocks with at least this many input channels (TS2D_WINO; 0 = off)
+    bool use_p = true;            // plane-layout stride-1 kernel (TS2D_P=0 falls back to conv3x3_f16x3_one)
     bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
     bool use_res = true;          // resident-weight kernel of the 32 -> 32 blocks (TS2D_RES=0 falls back)
     // workspace
@@ -229,6 +233,7 @@ int build_program(ts2d_engine* e) {
             const size_t recs = op.stride == 1 ? (size_t)(ct / 16) * 9 : (size_t)(ct / 8) * 5;
             op.dev_wh = wo; wo = align_up(wo + recs * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);                  // 1 / scale, read by the kernel
+            if (op.stride == 1) { op.dev_wp = wo; wo = align_up(wo + recs * op.cout * 16, 64); }      // plane order (conv3x3_f16x3_p)
             if (op.stride == 1 && ct % 16 == 0 && op.cout % 64 == 0 && op.cin % 16 == 0 && op.cin_skip % 16 == 0) {
                 op.wino_ok = true;
                 op.dev_wu = wo; wo = align_up(wo + (size_t)ct * op.cout * 16, 64);
@@ -358,6 +363,12 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                             const int chunk = ci / 16, cc = ci % 16, bn = co_n % 64 == 0 ? 64 : 32;
                             uint16_t* rec = d + ((((size_t)chunk * (co_n / bn) + co / bn) * 9 + tap) * bn + co % bn) * 32;
                             rec[cc] = hi; rec[16 + cc] = lo;
+                            {   // plane order of conv3x3_f16x3_p: [chunk][column tile][tap][hi,lo][h][column][8 halves]
+                                uint16_t* wp = reinterpret_cast<uint16_t*>(out + op.dev_wp);
+                                const size_t base = (((size_t)chunk * (co_n / bn) + co / bn) * 9 + tap) * 4;
+                                wp[((base + 0 + cc / 8) * bn + co % bn) * 8 + cc % 8] = hi;
+                                wp[((base + 2 + cc / 8) * bn + co % bn) * 8 + cc % 8] = lo;
+                            }
                             if (op.res_ok) {
                                 uint16_t* rw = reinterpret_cast<uint16_t*>(out + op.dev_wres);
                                 rw[((((size_t)tap * 2 + 0) * 4 + ci / 8) * 32 + co) * 8 + ci % 8] = hi;
@@ -530,6 +541,14 @@ hipError_t launch_one_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t
     auto kern = conv3x3_f16x3_one<BN, PFS>;
     if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(kern), attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
+    return hipGetLastError();
+}
+template <int BN, bool PFS>
+hipError_t launch_p_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    static std::atomic<uint64_t> attr_done{0};
+    auto kern = conv3x3_f16x3_p<BN, PFS>;
+    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(kern), attr_done); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid, 1), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
 template <int BN, bool PFS, bool PIPE, typename ST, int NP>
@@ -906,7 +925,13 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
             const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32;
             const bool one_s2 = split && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;
-            if (one) {     // tile inside one image: lean staging path
+            if (one && e->use_p && bn == 64 && Ht % 8 == 0 && Wt % 32 == 0 && g.lgTH == 3 && g.lgTW == 5) {
+                // complete 8 x 32 tiles x 64 columns: plane layout (conflict-free LDS; same speed as the record layout - measured;
+                // the 32-column variant lost its third workgroup per CU to registers and stays on conv3x3_f16x3_one)
+                ca.wph = wts + op.dev_wp;
+                const size_t smem_p = (size_t)4 * kPPlane + (size_t)9 * 4 * bn * 16;
+                le = launch_p_inst<64, true>(ca, grid, smem_p, st);
+            } else if (one) {     // tile inside one image: lean staging path
                 le = launch_one(bn, ca, grid, smem, st);
             } else if (one_s2) {
                 le = launch_one_s2(f16, bn, ca, grid, smem, st);
@@ -999,6 +1024,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_ONE")) e->use_one = getenv("TS2D_ONE")[0] == '1';
         if (getenv("TS2D_RES")) e->use_res = getenv("TS2D_RES")[0] == '1';
         if (getenv("TS2D_S2V2")) e->use_s2v2 = getenv("TS2D_S2V2")[0] == '1';
+        if (getenv("TS2D_P")) e->use_p = getenv("TS2D_P")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
         if (getenv("TS2D_WINO")) e->wino_min = atoi(getenv("TS2D_WINO"));
     }
