@@ -606,6 +606,13 @@ hipError_t launch_split_s2(bool f16, int bn, int maxu, const ConvArgs& a, int gr
     return f16 ? launch_split_s2_t<_Float16, 1>(bn, maxu, a, grid, smem, st) : launch_split_s2_t<float, 3>(bn, maxu, a, grid, smem, st);
 }
 
+// per-tile partials -> scale / shift; the tile-lane count depends on the layer geometry only (never on B)
+template <typename... A>
+void launch_finalize(int B, int cout, hipStream_t st, const float* part, int ntiles, A... rest) {
+    if (ntiles >= 128) hipLaunchKernelGGL(finalize_stats_t<32>, dim3(B, cout / 32), dim3(1024), 0, st, part, ntiles, rest...);
+    else hipLaunchKernelGGL(finalize_stats_t<8>, dim3(B, cout / 32), dim3(256), 0, st, part, ntiles, rest...);
+}
+
 void launch_stats_direct(bool f16, int B, int C, int HW, const float* x, const float* g, const float* be, float eps, float* sc, float* sh, hipStream_t st) {
     if (f16) hipLaunchKernelGGL(stats_direct<_Float16>, dim3(B, C / 32), dim3(256), 0, st, reinterpret_cast<const _Float16*>(x), C, HW, g, be, eps, sc, sh);
     else hipLaunchKernelGGL(stats_direct<float>, dim3(B, C / 32), dim3(256), 0, st, x, C, HW, g, be, eps, sc, sh);
@@ -770,7 +777,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             TRY(prof_end(e, st));
             TRY(prof_begin(e, op.name + ".stats", st));
             if (fused)
-                hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
+                launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
                                    op.cout, B, H * W, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
             else
                 launch_stats_direct(f16, B, op.cout, H * W, dst.data, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift, st);
@@ -819,7 +826,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
                 TRY(prof_begin(e, op.name + ".stats", st));
-                hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
+                launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
                                    op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
@@ -844,7 +851,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
                 TRY(prof_begin(e, op.name + ".stats", st));
-                hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
+                launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
                                    op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
@@ -877,7 +884,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
                 TRY(prof_begin(e, op.name + ".stats", st));
-                hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, tpi_r,
+                launch_finalize(B, op.cout, st, e->d_part, tpi_r,
                                    op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
@@ -955,7 +962,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                     else hipLaunchKernelGGL(splitk_reduce_stats<float>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, ksplit, ca.kslice_stride,
                                             wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.data, dst.scale, dst.shift);
                 } else if (fused) {
-                    hipLaunchKernelGGL(finalize_stats, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_part, g.tiles_x * g.tiles_y,
+                    launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
                                        op.cout, B, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 } else {
                     launch_stats_direct(f16, B, op.cout, HW, dst.data, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift, st);

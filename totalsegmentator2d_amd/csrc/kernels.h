@@ -274,20 +274,22 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
 // InstanceNorm statistics -> per-(n,c) scale/shift.  scale = gamma * rstd, shift = beta - mean * scale,
 // biased variance, eps inside the sqrt, combined in double.
 // ------------------------------------------------------------------------------------------------------------
-// (a) from the conv epilogue's per-tile partial (sum, sum of squares): one thread per (n, c).
-// Grid (B, C/32), 256 threads = 8 tile lanes x 32 channels; fixed summation order -> bit-reproducible.
-__global__ __launch_bounds__(256) void finalize_stats(const float* __restrict__ part, int ntiles, int C, int B, int HW,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float eps, float* __restrict__ scale, float* __restrict__ shift) {
+// (a) from the conv epilogue's per-tile partial (sum, sum of squares).  Grid (B, C/32), 32 TL threads = TL tile lanes x 32
+// channels (TL = 32 for the levels with hundreds of tiles per image: a 64-block grid is latency-bound, so each block brings 1024
+// threads; TL = 8 otherwise); fixed summation order -> bit-reproducible, and independent of the batch a slice travels in.
+template <int TL>
+__global__ __launch_bounds__(32 * TL) void finalize_stats_t(const float* __restrict__ part, int ntiles, int C, int B, int HW,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float* __restrict__ scale, float* __restrict__ shift) {
     const int n = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, tl = threadIdx.x >> 5;
-    __shared__ double rs[8][32], rq[8][32];
+    __shared__ double rs[TL][32], rq[TL][32];
     const float2* p = reinterpret_cast<const float2*>(part) + (size_t)n * ntiles * C + c;
     double s = 0.0, q = 0.0;
-    for (int t = tl; t < ntiles; t += 8) { const float2 v = p[(size_t)t * C]; s += (double)v.x; q += (double)v.y; }
+    for (int t = tl; t < ntiles; t += TL) { const float2 v = p[(size_t)t * C]; s += (double)v.x; q += (double)v.y; }
     rs[tl][cl] = s; rq[tl][cl] = q;
     __syncthreads();
     if (tl == 0) {
-        for (int k = 1; k < 8; ++k) { s += rs[k][cl]; q += rq[k][cl]; }
+        for (int k = 1; k < TL; ++k) { s += rs[k][cl]; q += rq[k][cl]; }
         const double mean = s / HW;
         double var = q / HW - mean * mean;
         var = var > 0.0 ? var : 0.0;
