@@ -34,6 +34,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak (same guide); the split path issues 3 fp16 MFMA products per MAC
 MEASURED_F16_PIPE_TFLOPS = 32768 * 1024 / 20.8e-9 / 1e12      # 32x32x16 MFMA = 32768 FLOP, 1024 SIMDs, 20.8 ns each (probe): ~1613
 PEAK_HBM_GBS = 8000.0
+MEASURED_HBM_MIXED_GBS = 4700.0   # copy / 4:3 read:write streaming rate measured on this pool (scripts/probes/hbm_probe.hip)
 
 
 def host_cores() -> int:
@@ -308,40 +309,66 @@ def main():
                         'f16': 'f16 storage + f16 MFMA, f32 accumulate/statistics (NOT within the fp32 parity tolerance)'}[args.precision]
         out['precision_mode'] = args.precision
         if profile and op_ms:
-            # dominant kernel = the stride-1 3x3 implicit-GEMM conv (conv3x3_f16x3_one + conv3x3_f16x3 on the 8x8/4x4 levels /
-            # conv3x3_h32 / conv_mfma_f32<9,1,..>): 22 launches/step
             prog = arch.program()
-            per = {o['name']: 2.0 * m['macs'] for o, m in zip(prog, work['per_layer'])
-                   if o['op'] == OP_CONV3X3 and o['stride'] == 1 and o['src'] != 'input'}
-            conv_ms = sum(v for k, v in op_ms.items() if k in per) / args.steps
+            layer = {o['name']: (o, m) for o, m in zip(prog, work['per_layer'])}
+            ms = {k: v / args.steps for k, v in op_ms.items()}
+            # (a) the stride-1 3x3 family of round 1 (22 launches/step, 83 % of the FLOPs), kept for continuity
+            per = {n: 2.0 * m['macs'] for n, (o, m) in layer.items() if o['op'] == OP_CONV3X3 and o['stride'] == 1 and o['src'] != 'input'}
+            conv_ms = sum(ms[k] for k in per if k in ms)
             conv_flops = sum(per.values()) * B
-            achieved = conv_flops / (conv_ms * 1e-3) / 1e12
             peak = {'split': PEAK_F16_MFMA_TFLOPS / 3.0, 'exact': PEAK_FP32_MFMA_TFLOPS, 'f16': PEAK_F16_MFMA_TFLOPS}[args.precision]
+            # (b) the DOMINANT KERNEL: the 64-column stride-1 kernel of levels 1-4 (complete 8 x 32 tiles; 12 launches/step) - MFMA-bound
+            dom = [n for n, (o, m) in layer.items() if n in per and o['cout'] >= 64 and (H >> o['level']) >= 32]
+            dom_ms = sum(ms[k] for k in dom if k in ms)
+            dom_flops = sum(per[k] for k in dom) * B
+            achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+            dom_kernel = {'split': 'conv3x3_f16x3_p<64>', 'f16': 'conv3x3_h32<64>', 'exact': 'conv_mfma_f32<9,1,16,64>'}[args.precision]
             traffic, traffic_stale = None, None
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(pmc):
                 try:
                     pj = json.load(open(pmc))
                     traffic_stale = pj.get('csrc_hash') != csrc_hash()          # measured on other kernel sources: do not report it
-                    traffic = None if traffic_stale else pj.get(f'conv3x3_s1_{args.precision}_hbm_bytes_per_launch_avg')
+                    traffic = None if traffic_stale else pj.get('hbm_bytes_per_launch_avg', {}).get(dom_kernel)
                 except Exception:
                     traffic = None
             all3 = {o['name'] for o in prog if o['op'] == OP_CONV3X3}
+            pipe = MEASURED_F16_PIPE_TFLOPS / (3.0 if split else 1.0)
             out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                                'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_stale': traffic_stale,
-                               'kernel': {'split': 'conv3x3_f16x3_one (18) + conv3x3_f16x3 (4)', 'f16': 'conv3x3_h32 (18) + conv3x3_f16x3<f16> (4)',
-                                          'exact': 'conv_mfma_f32<9,1,16,*>'}[args.precision] + f' ({len(per)} launches/step)',
-                               'peak_note': ('dense fp16 MFMA 2500 TFLOP/s / 3 products per MAC' if split else 'fp32 MFMA 32x32x2'),
-                               # profiles/r01_mfma_coissue_probe.txt: a bare v_mfma_f32_32x32x16_f16 stream on every SIMD runs at
-                               # 20.5-21 ns per MFMA (= 32 cycles at the ~1.52 GHz this chip sustains under dense matrix load)
-                               'frac_of_measured_matrix_pipe_rate': (round(achieved / (MEASURED_F16_PIPE_TFLOPS / (3.0 if split else 1.0)), 4)
-                                                                     if args.precision in ('split', 'f16') else None),
-                               'algorithmic_flop_per_launch_avg': round(conv_flops / len(per)),
-                               'kernel_ms_per_launch_avg': round(conv_ms / len(per), 4),
-                               'kernel_ms_per_step': round(conv_ms, 3), 'kernel_share_of_step': round(conv_ms / ms_per_step, 4),
-                               'all_conv3x3_ms_per_step': round(sum(v for k, v in op_ms.items() if k in all3) / args.steps, 3),
-                               'whole_step_hbm_frac_layerwise': round(value / world * work['act_bytes'] / 1e9 / PEAK_HBM_GBS, 4),
-                               'whole_step_fp32_mfma_equiv_frac': round(value / world * work['flops'] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+                               'kernel': f'{dom_kernel} ({len(dom)} launches/step: stride-1 3x3 blocks of levels 1-4)',
+                               'peak_note': ('dense fp16 MFMA 2500 TFLOP/s / 3 products per MAC' if split else
+                                             ('dense fp16 MFMA' if args.precision == 'f16' else 'fp32 MFMA 32x32x2')),
+                               # profiles/r01_mfma_coissue_probe.txt, scripts/probes/mfma_shape_probe.hip: a bare v_mfma_f32_32x32x16_f16
+                               # stream on every SIMD runs at 20.5-21 ns per MFMA (= 32 cycles at the ~1.5 GHz held under matrix load)
+                               'frac_of_measured_matrix_pipe_rate': round(achieved / pipe, 4) if args.precision in ('split', 'f16') else None,
+                               'algorithmic_flop_per_launch_avg': round(dom_flops / len(dom)),
+                               'kernel_ms_per_launch_avg': round(dom_ms / len(dom), 4),
+                               'kernel_ms_per_step': round(dom_ms, 3), 'kernel_share_of_step': round(dom_ms / ms_per_step, 4)}
+            fam = conv_flops / (conv_ms * 1e-3) / 1e12
+            out['roofline_stride1_family'] = {'bound': 'mfma', 'achieved': round(fam, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                                              'frac': round(fam / peak, 4), 'launches_per_step': len(per), 'ms_per_step': round(conv_ms, 3),
+                                              'note': 'all 22 stride-1 3x3 launches (round-1 definition); its level-0 members are HBM-bound, see roofline_level0',
+                                              'all_conv3x3_ms_per_step': round(sum(ms[k] for k in all3 if k in ms), 3)}
+            # (c) level 0 + head: HBM-bound.  Algorithmic bytes = one read of every input (no halo), one write of the output.
+            esz = 2 if args.precision == 'f16' else 4
+            l0 = {}
+            for n, (o, m) in layer.items():
+                if o['level'] == 0 and n in ms:
+                    cin = o['cin'] + o.get('cin_skip', 0)
+                    px_in = (H * W) if o['op'] != 1 else (H * W) // 4          # transposed conv reads the level below
+                    rd = px_in * cin * (4 if o['src'] == 'input' else esz)
+                    wr = H * W * o['cout'] * (4 if n == 'head' else esz)
+                    l0[n] = (rd + wr) * B
+            l0_ms = sum(ms[k] for k in l0)
+            l0_gbs = sum(l0.values()) / (l0_ms * 1e-3) / 1e9
+            out['roofline_level0'] = {'bound': 'hbm', 'achieved': round(l0_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                      'frac': round(l0_gbs / PEAK_HBM_GBS, 4), 'ops': sorted(l0), 'ms_per_step': round(l0_ms, 3),
+                                      'frac_of_measured_mixed_read_write_rate': round(l0_gbs / MEASURED_HBM_MIXED_GBS, 4),
+                                      'note': 'scripts/probes/hbm_probe.hip on this pool: read-only 6.47, write-only 5.6, copy 4.7, 4:3 read:write '
+                                              '4.6 TB/s; the achieved figure counts algorithmic bytes (halo re-reads not included)'}
+            out['whole_step'] = {'hbm_frac_layerwise': round(value / world * work['act_bytes'] / 1e9 / PEAK_HBM_GBS, 4),
+                                 'fp32_mfma_equiv_frac': round(value / world * work['flops'] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
             top = sorted(op_ms.items(), key=lambda kv: -kv[1])[:8]
             out['top_ops_ms'] = {k: round(v / args.steps, 3) for k, v in top}
         if world == 1 and not args.no_other_modes:
