@@ -17,7 +17,7 @@ with Engine(arch, blob) as e:
     e.set_precision(mode)
     import torch
     lgt, _ = e.forward(torch.from_numpy(x).cuda()); torch.cuda.synchronize(); lg = lgt.cpu().numpy()      # (device path: no automatic finite check)
-    for name in ('enc0.c0', 'enc0.c1', 'enc1.c0', 'enc1.c1', 'dec0.up', 'dec0.c0', 'dec0.c1'):
+    for name in ('enc0.c0', 'enc0.c1', 'enc1.c0', 'enc1.c1', 'dec0.c0', 'dec0.c1'):
         t = e.debug_tensor(name)
         r = inter[name].numpy()
         d = np.abs(np.nan_to_num(t, nan=1e9, posinf=1e9, neginf=1e9) - r)

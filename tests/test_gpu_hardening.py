@@ -47,13 +47,21 @@ def test_weights_spanning_twenty_binades_in_one_layer():
     assert np.isfinite(lg).all() and _rel_err(lg, ref) <= 1e-4
 
 
-def test_overflowing_transposed_conv_output_is_an_error_naming_the_layer():
+def test_overflowing_transposed_conv_output_is_an_error_naming_the_layer(monkeypatch):
     arch, sd, x = _case()
     blob_ok = weights.pack_blob(arch, sd)
     sd = dict(sd)
     key = 'decoder.transpconvs.1.weight'
     sd[key] = sd[key] * np.float32(3e5)                    # un-normalised output of dec1.up far beyond 65504
     blob = weights.pack_blob(arch, sd)
+    ref = O.unet_forward(arch, sd, x).numpy()
+    with Engine(arch, blob) as e:
+        # default path: the transposed conv is COMPOSED into dec1.c0 (kernels_upc.h) - its un-normalised output never exists as
+        # an fp16 operand, the composed weights carry their own power-of-two pre-scale: finite and right
+        lg, _ = e.forward(x)                               # (level 1 of this case is 32 x 32: complete tiles, composed)
+        assert not e.materialised('dec1.up')
+        assert np.isfinite(lg).all() and _rel_err(lg, ref) <= 1e-4
+    monkeypatch.setenv('TS2D_UPC', '0')                    # two-kernel path: the overflow is detected and named
     with Engine(arch, blob) as e:
         with pytest.raises(RuntimeError, match=r'non-finite logits: inf / NaN first appears in layer dec1\.c0'):
             e.forward(x)                                   # host-buffer forward runs ts2d_engine_check itself
@@ -64,7 +72,6 @@ def test_overflowing_transposed_conv_output_is_an_error_naming_the_layer():
         e.set_precision('exact')                           # the fp32 MFMA path has no fp16 range limit
         lg, _ = e.forward(x)
         assert np.isfinite(lg).all()
-        ref = O.unet_forward(arch, sd, x).numpy()
         assert _rel_err(lg, ref) <= 1e-4
         e.set_precision('split')
         e.load_weights(blob_ok)                            # the flag does not stick: sane weights, same engine

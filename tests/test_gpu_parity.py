@@ -20,7 +20,7 @@ def _oracle_mask(logits):
 
 
 @pytest.mark.parametrize('name', list(cases.SMALL_CASES))
-def test_logits_and_masks_match_goldens(name):
+def test_logits_and_masks_match_goldens(name, monkeypatch):
     arch, B, H, W, seed = cases.SMALL_CASES[name]
     _, blob = blob_for(arch, seed)
     x = cases.make_input(arch, B, H, W, seed)
@@ -39,10 +39,20 @@ def test_logits_and_masks_match_goldens(name):
             assert np.array_equal(unpack_mask(mk, W), _oracle_mask(lg))            # bit-exact on the same logits
             disagree = int((mk.view(np.uint32) != g['mask_packed']).sum())
             assert disagree <= max(2, lg.size // 20000)                              # vs oracle end-to-end: only |logit| ~ 1e-5 flips
-        for k in g.files:                                                             # per-kernel parity K1..K7
-            if k.startswith('inter/'):
+        inter = [k for k in g.files if k.startswith('inter/')]
+        composed = [k for k in inter if k.endswith('.up') and not e.materialised(k[6:])]   # K5 composed into K6 (kernels_upc.h)
+        for k in inter:                                                               # per-kernel parity K1..K7
+            if k not in composed:
                 t = e.debug_tensor(k[6:])
                 assert t.shape == g[k].shape and np.abs(t - g[k]).max() <= TOL, k
+    if composed:                                                                      # K5 on its own kernel: two-kernel path
+        monkeypatch.setenv('TS2D_UPC', '0')
+        with Engine(arch, blob) as e:
+            lg0, _ = e.forward(x, logits=True)
+            for k in inter:
+                t = e.debug_tensor(k[6:])
+                assert t.shape == g[k].shape and np.abs(t - g[k]).max() <= TOL, k
+            assert np.abs(lg0 - lg).max() <= 3e-5
 
 
 def test_canonical_net_512_golden():
@@ -222,8 +232,9 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
     with Engine(arch, blob) as e:                          # default path: includes the resident-weight 32 -> 32 kernel
         lgr, _ = e.forward(x, logits=True)
         tr = {n: e.debug_tensor(n) for n in names}
-    monkeypatch.setenv('TS2D_RES', '0')                    # (conv3x3_res32 and conv3x3s2_v2 sum in another order: compared by value below)
+    monkeypatch.setenv('TS2D_RES', '0')                    # (conv3x3_res32, conv3x3s2_v2 and conv3x3_upc sum in another order: compared by value below)
     monkeypatch.setenv('TS2D_S2V2', '0')
+    monkeypatch.setenv('TS2D_UPC', '0')
     with Engine(arch, blob) as e:
         lg1, _ = e.forward(x, logits=True)
         t1 = {n: e.debug_tensor(n) for n in names}
@@ -234,11 +245,47 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
     for n in names:
         assert np.array_equal(t0[n], t1[n]), n
     assert np.abs(lg0 - lg1).max() <= 1e-5
-    # conv3x3_res32 (one 288-term accumulation per output instead of two 144-term chunks) and conv3x3s2_v2 (16-channel chunks,
-    # one tap per k-step): same values to fp32 rounding
+    # conv3x3_res32 (one 288-term accumulation per output instead of two 144-term chunks), conv3x3s2_v2 (16-channel chunks,
+    # one tap per k-step) and conv3x3_upc (transposed conv composed into the block): same values to fp32 rounding
     for n in names:
         assert np.abs(tr[n] - t1[n]).max() <= 2e-5, n
     assert np.abs(lgr - lg1).max() <= 2e-5
+
+
+def test_composed_upsampling_block_matches_the_two_kernel_path_and_the_oracle(monkeypatch):
+    """kernels_upc.h: ConvTranspose2d composed into the "up" half of the next 3x3 conv (parity-specific 2x2 weights over the
+    coarse tensor, nine bias variants for the image border).  Checked against the two-kernel path (TS2D_UPC=0) layer by layer and
+    against the torch oracle, with the transposed conv's BIAS blown up so that a wrong border variant cannot hide, on extents
+    where some levels compose (complete 8 x 32 tiles) and others do not, one and several tiles per image, BN = 32 and 64."""
+    from oracle import torch_oracle as O
+    from totalsegmentator2d_amd import weights
+    runs = ((cases.unet(4, (32, 64, 128, 128), 6, cin=2), 3, 64, 128, 31),        # levels 0-2 compose, level 2 has ONE tile per image
+            (cases.unet(3, (64, 64, 128), 5, cin=1), 2, 32, 64, 32),              # BN = 64 at level 0; level 1 (16 x 32) composes
+            (cases.unet(3, (32, 64, 128), 3, cin=1, nconv=1), 1, 256, 256, 33))   # many tiles per image
+    for arch, B, H, W, seed in runs:
+        sd = weights.synthetic_state_dict(arch, seed)
+        for k in sd:
+            if 'transpconvs' in k and k.endswith('bias'):
+                sd[k] = (sd[k] * 40.0).astype(np.float32)
+        blob = weights.pack_blob(arch, sd)
+        x = cases.make_input(arch, B, H, W, seed)
+        ref = O.unet_forward(arch, sd, x).numpy()
+        names = [f'dec{l}.c0' for l in range(arch.n_stages - 1)]
+        monkeypatch.delenv('TS2D_UPC', raising=False)
+        with Engine(arch, blob) as e:
+            lg1, _ = e.forward(x, logits=True)
+            t1 = {n: e.debug_tensor(n) for n in names}
+            with pytest.raises(Exception, match='not materialised'):
+                e.debug_tensor('dec0.up')
+            e.check()
+        monkeypatch.setenv('TS2D_UPC', '0')
+        with Engine(arch, blob) as e:
+            lg0, _ = e.forward(x, logits=True)
+            t0 = {n: e.debug_tensor(n) for n in names}
+            e.debug_tensor('dec0.up')
+        for n in names:
+            assert np.abs(t1[n] - t0[n]).max() <= 3e-5, (n, float(np.abs(t1[n] - t0[n]).max()))
+        assert np.abs(lg1 - ref).max() <= TOL and np.abs(lg0 - ref).max() <= TOL
 
 
 def test_randomised_shapes_against_the_torch_oracle():

@@ -13,6 +13,7 @@
 #include "kernels_res32.h"
 #include "kernels_s2v2.h"
 #include "kernels_wino.h"
+#include "kernels_upc.h"
 #include "kernels_sw.h"
 #include "kernels_project.h"
 
@@ -78,6 +79,12 @@ struct Op {
     int bn2 = 0;                  // its column tile (128 or 64)
     bool res_ok = false;          // 32 -> 32 stride-1 block: resident-weight persistent kernel (kernels_res32.h)
     size_t dev_wres = 0;          // offset (floats) of its weight image [tap][hi,lo][g][cout][8 halves]
+    bool upc_ok = false;          // decoder c0 block whose "up" half is composed with the preceding ConvTranspose2d (kernels_upc.h)
+    int up_idx = -1;              // ... index of that transposed conv in the program
+    size_t dev_wc = 0;            // composed weights [chunk Cb/16][column tile][16 = (A,B,dI,dJ)][hi,lo][h][column][8 halves]
+    size_t dev_wk = 0;            // skip half of the 3x3 weights [chunk Cs/16][column tile][tap][hi,lo][h][column][8 halves]
+    size_t dev_wcs = 0;           // 1 / (their common power-of-two pre-scale)
+    size_t dev_bvar = 0;          // [9 = (ry, rx)][Cout] bias variants
     bool first_direct = false;    // first conv block handled by conv3x3_first (reads the NCHW boundary tensor)
     size_t dev_wraw = 0;
 };
@@ -122,6 +129,8 @@ struct ts2d_engine {
     int wino_min = 0;             // Winograd kernel for stride-1 blocks with at least this many input channels (TS2D_WINO; 0 = off)
     bool use_p = true;            // plane-layout stride-1 kernel (TS2D_P=0 falls back to conv3x3_f16x3_one)
     bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
+    bool use_upc = true;          // decoder c0 blocks composed with their transposed conv (TS2D_UPC=0 falls back to two kernels)
+    std::vector<char> fused_away; // per op of the last run: 1 = its output tensor was not materialised (composed into the next op)
     bool use_res = true;          // resident-weight kernel of the 32 -> 32 blocks (TS2D_RES=0 falls back)
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
@@ -246,6 +255,17 @@ int build_program(ts2d_engine* e) {
             if (op.stride == 1 && ct == 32 && op.cout == 32) {      // resident image of the 32 -> 32 block: [tap][hi,lo][g][cout][8 halves]
                 op.res_ok = true;
                 op.dev_wres = wo; wo = align_up(wo + 9 * 2 * 4 * 32 * 8 / 2, 64);
+            }
+            const size_t oi = (size_t)(&op - e->ops.data());
+            if (op.stride == 1 && op.skip >= 0 && oi > 0 && e->ops[oi - 1].type == OP_CONVT && e->ops[oi - 1].dst == op.src &&
+                e->ops[oi - 1].cin % 16 == 0 && op.cin % 16 == 0 && op.cin_skip % 16 == 0 && op.cout % 32 == 0 &&
+                (double)op.cout * e->ops[oi - 1].cin * op.cin * 36.0 <= 6.0e9) {        // (host composition cost bound: 512 x 512 x 512 channels = 4.8 GFLOP, about a second)
+                const int cb = e->ops[oi - 1].cin;
+                op.upc_ok = true; op.up_idx = (int)oi - 1;
+                op.dev_wc = wo; wo = align_up(wo + (size_t)cb * op.cout * 16, 64);
+                op.dev_wk = wo; wo = align_up(wo + (size_t)op.cin_skip * op.cout * 9, 64);
+                op.dev_wcs = wo; wo = align_up(wo + 1, 64);
+                op.dev_bvar = wo; wo = align_up(wo + (size_t)9 * op.cout, 64);
             }
             if (op.stride == 1 && op.cin % 32 == 0 && op.cin_skip % 32 == 0) {      // [chunk32][column tile][tap][column][32 halves]
                 op.h32_ok = true;
@@ -389,6 +409,87 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                             rec[cc] = hi; rec[16 + cc] = lo;
                         }
                     }
+                }
+        }
+    }
+    for (const Op& op : e->ops) {
+        if (!op.upc_ok) continue;
+        // ConvTranspose2d (2x2, stride 2) composed with the "up" half of the following 3x3 conv (kernels_upc.h), in fp64:
+        //   Weff[A][B][dI][dJ][co][cb] = sum_{(ky,kx) -> (dI,dJ)} sum_cu W3[co][cu][ky][kx] WT[cb][cu][a][b]
+        // with, for output parity A and tap ky: up row 2I + A + ky - 1 = 2 (I + A - 1 + dI) + a.
+        const Op& up = e->ops[op.up_idx];
+        const int cb_n = up.cin, cu_n = op.cin, cs_n = op.cin_skip, ct = cu_n + cs_n, co_n = op.cout;
+        const float* w3 = blob + op.blob_w;          // [co][ct][3][3], channels 0 .. cu_n-1 = the upsampled half (torch.cat((up, skip), 1))
+        const float* wt = blob + up.blob_w;          // [cb][cu][2][2]
+        const float* bt = blob + up.blob_b;
+        std::vector<double> R((size_t)4 * cu_n * cb_n);              // R[ab][cu][cb]
+        for (int cb = 0; cb < cb_n; ++cb)
+            for (int cu = 0; cu < cu_n; ++cu)
+                for (int ab = 0; ab < 4; ++ab) R[((size_t)ab * cu_n + cu) * cb_n + cb] = wt[((size_t)cb * cu_n + cu) * 4 + ab];
+        std::vector<double> Weff((size_t)16 * co_n * cb_n, 0.0);     // [tapidx = (A*2+B)*4 + dI*2+dJ][co][cb]
+        for (int A = 0; A < 2; ++A)
+            for (int Bp = 0; Bp < 2; ++Bp)
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int fy = (A + ky + 1) / 2 - 1, fx = (Bp + kx + 1) / 2 - 1;          // floor((A + ky - 1) / 2)
+                        const int dI = fy - A + 1, dJ = fx - Bp + 1, ta = (A + ky + 1) & 1, tb = (Bp + kx + 1) & 1;
+                        double* acc = Weff.data() + (size_t)((A * 2 + Bp) * 4 + dI * 2 + dJ) * co_n * cb_n;
+                        const double* Rm = R.data() + (size_t)(ta * 2 + tb) * cu_n * cb_n;
+                        for (int co = 0; co < co_n; ++co) {
+                            double* arow = acc + (size_t)co * cb_n;
+                            for (int cu = 0; cu < cu_n; ++cu) {
+                                const double l = w3[((size_t)co * ct + cu) * 9 + ky * 3 + kx];
+                                const double* rrow = Rm + (size_t)cu * cb_n;
+                                for (int cb = 0; cb < cb_n; ++cb) arow[cb] += l * rrow[cb];
+                            }
+                        }
+                    }
+        double mx = 0.0;
+        for (double v : Weff) mx = std::max(mx, std::fabs(v));
+        for (int co = 0; co < co_n; ++co)
+            for (int cs = 0; cs < cs_n; ++cs)
+                for (int tap = 0; tap < 9; ++tap) mx = std::max(mx, (double)std::fabs(w3[((size_t)co * ct + cu_n + cs) * 9 + tap]));
+        const float wscale = (mx > 0.0 && std::isfinite(mx)) ? std::exp2(std::floor(std::log2(16383.0 / mx))) : 1.f;
+        out[op.dev_wcs] = 1.0f / wscale;
+        const int bn = co_n % 64 == 0 ? 64 : 32, nct = co_n / bn;
+        uint16_t* dc = reinterpret_cast<uint16_t*>(out + op.dev_wc);
+        for (int t = 0; t < 16; ++t)
+            for (int co = 0; co < co_n; ++co)
+                for (int cb = 0; cb < cb_n; ++cb) {
+                    const float v = (float)(Weff[((size_t)t * co_n + co) * cb_n + cb] * (double)wscale);
+                    const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                    const size_t base = (((size_t)(cb / 16) * nct + co / bn) * 16 + t) * 4;
+                    const int hh = (cb % 16) / 8;
+                    dc[((base + 0 + hh) * bn + co % bn) * 8 + cb % 8] = hi;
+                    dc[((base + 2 + hh) * bn + co % bn) * 8 + cb % 8] = lo;
+                }
+        uint16_t* dk = reinterpret_cast<uint16_t*>(out + op.dev_wk);
+        for (int co = 0; co < co_n; ++co)
+            for (int cs = 0; cs < cs_n; ++cs)
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float v = w3[((size_t)co * ct + cu_n + cs) * 9 + tap] * wscale;
+                    const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                    const size_t base = (((size_t)(cs / 16) * nct + co / bn) * 9 + tap) * 4;
+                    const int hh = (cs % 16) / 8;
+                    dk[((base + 0 + hh) * bn + co % bn) * 8 + cs % 8] = hi;
+                    dk[((base + 2 + hh) * bn + co % bn) * 8 + cs % 8] = lo;
+                }
+        // bias variants: the transposed conv's bias reaches an output pixel through the taps that lie inside the image
+        float* bv = out + op.dev_bvar;
+        for (int co = 0; co < co_n; ++co) {
+            double bc[3][3];
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    double acc = 0.0;
+                    for (int cu = 0; cu < cu_n; ++cu) acc += (double)w3[((size_t)co * ct + cu) * 9 + ky * 3 + kx] * (double)bt[cu];
+                    bc[ky][kx] = acc;
+                }
+            for (int ry = 0; ry < 3; ++ry)
+                for (int rx = 0; rx < 3; ++rx) {
+                    double acc = (double)blob[op.blob_b + co];
+                    for (int ky = (ry == 0 ? 1 : 0); ky < (ry == 2 ? 2 : 3); ++ky)
+                        for (int kx = (rx == 0 ? 1 : 0); kx < (rx == 2 ? 2 : 3); ++kx) acc += bc[ky][kx];
+                    bv[(size_t)(ry * 3 + rx) * co_n + co] = (float)acc;
                 }
         }
     }
@@ -732,9 +833,22 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
     return rc != TS2D_OK ? rc : rc2;
 }
 
+// Does the decoder block `op` (3x3 conv over cat(up, skip)) run as ONE kernel together with its transposed conv for this geometry?
+bool upc_applies(const ts2d_engine* e, const Op& op, int B, int H, int W) {
+    if (!op.upc_ok || !e->use_upc || !e->use_one || e->precision != TS2D_PRECISION_F32_SPLIT_F16X3) return false;
+    const int Ht = H >> op.level, Wt = W >> op.level;
+    if (Ht % 8 || Wt % 32) return false;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const int bn = op.cout % 64 == 0 ? 64 : 32;
+    if (!pow2(Wt / 32) || !pow2((Wt / 32) * (Ht / 8)) || !pow2(op.cout / bn)) return false;
+    const size_t lim = (size_t)1 << 31;
+    return (size_t)Ht * Wt * std::max(op.cout, op.cin_skip) * 4 < lim && (size_t)(Ht / 2) * (Wt / 2) * e->ops[op.up_idx].cin * 4 < lim && B > 0;
+}
+
 int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st) {
     const ts2d_arch_desc& a = e->arch;
     e->n_launched = 0;
+    e->fused_away.assign(e->ops.size(), 0);
     // (the input is scanned by ts2d_engine_check only when it lives in the engine's own staging memory)
     e->last_input = (d_in == e->d_in_stage || (e->d_sw && reinterpret_cast<const char*>(d_in) >= e->d_sw &&
                                                reinterpret_cast<const char*>(d_in) < e->d_sw + e->sw_bytes)) ? d_in : nullptr;
@@ -781,6 +895,45 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                                    op.cout, B, H * W, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
             else
                 launch_stats_direct(f16, B, op.cout, H * W, dst.data, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift, st);
+            HIP_TRY(hipGetLastError());
+            TRY(prof_end(e, st));
+            continue;
+        }
+        const size_t oi = (size_t)(&op - e->ops.data());
+        if (op.type == OP_CONVT && oi + 1 < e->ops.size() && e->ops[oi + 1].up_idx == (int)oi && upc_applies(e, e->ops[oi + 1], B, H, W)) {
+            e->fused_away[oi] = 1;          // composed into the next block (kernels_upc.h): the upsampled tensor is never materialised
+            continue;
+        }
+        if (op.type == OP_CONV && op.up_idx >= 0 && e->fused_away[op.up_idx]) {
+            const Op& up = e->ops[op.up_idx];
+            const Tensor& xc = e->tensors[up.src]; const Tensor& sk = e->tensors[op.skip]; Tensor& dst = e->tensors[op.dst];
+            const int Ht = H >> op.level, Wt = W >> op.level, bn = op.cout % 64 == 0 ? 64 : 32;
+            UpcArgs ua{};
+            ua.xc = xc.data; ua.scc = xc.scale; ua.shc = xc.shift; ua.Cb = up.cin;
+            ua.xs = sk.data; ua.scs = sk.scale; ua.shs = sk.shift; ua.Cs = op.cin_skip;
+            ua.wc = wts + op.dev_wc; ua.wk = wts + op.dev_wk; ua.bvar = wts + op.dev_bvar; ua.oscale = wts + op.dev_wcs;
+            ua.dst = dst.data; ua.part = e->d_part;
+            ua.B = B; ua.H = Ht; ua.W = Wt; ua.Cout = op.cout;
+            ua.tiles_x = Wt / 32; ua.tiles_y = Ht / 8; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y; ua.n_ctiles = op.cout / bn;
+            ua.lg_nct = ilog2(ua.n_ctiles); ua.lg_tx = ilog2(ua.tiles_x); ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
+            ua.slope = a.leaky_slope;
+            const int grid = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
+            const size_t smem_u = std::max((size_t)4 * kUcPlane + (size_t)16 * 4 * bn * 16, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
+            TRY(prof_begin(e, op.name, st));
+            if (bn == 64) {
+                static std::atomic<uint64_t> done64{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<64>), done64));
+                hipLaunchKernelGGL(conv3x3_upc<64>, dim3(grid), dim3(kBlock), smem_u, st, ua);
+            } else {
+                static std::atomic<uint64_t> done32{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<32>), done32));
+                hipLaunchKernelGGL(conv3x3_upc<32>, dim3(grid), dim3(kBlock), smem_u, st, ua);
+            }
+            HIP_TRY(hipGetLastError());
+            TRY(prof_end(e, st));
+            TRY(prof_begin(e, op.name + ".stats", st));
+            launch_finalize(B, op.cout, st, e->d_part, ua.tiles_x * ua.tiles_y,
+                               op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
             continue;
@@ -1032,6 +1185,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_RES")) e->use_res = getenv("TS2D_RES")[0] == '1';
         if (getenv("TS2D_S2V2")) e->use_s2v2 = getenv("TS2D_S2V2")[0] == '1';
         if (getenv("TS2D_P")) e->use_p = getenv("TS2D_P")[0] == '1';
+        if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
         if (getenv("TS2D_WINO")) e->wino_min = atoi(getenv("TS2D_WINO"));
     }
@@ -1216,6 +1370,8 @@ int ts2d_engine_check(ts2d_engine* e) {
     else
         for (const Op& op : e->ops) {
             if (op.dst < 0) continue;
+            const size_t oi = (size_t)(&op - e->ops.data());
+            if (oi < e->fused_away.size() && e->fused_away[oi]) continue;        // not materialised in the last run
             const Tensor& t = e->tensors[op.dst];
             const size_t n = (size_t)B * (H >> t.level) * (W >> t.level) * t.C;
             const int f = has_nonfinite(t.data, n, e->last_f16);
@@ -1310,6 +1466,10 @@ int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_
     const int ti = tensor_index(e, name);
     if (ti < 0 || !e->lastB) return fail(TS2D_ERR_INVALID, "no tensor '%s' (or no forward has run)", name);
     const Tensor& t = e->tensors[ti];
+    for (size_t oi = 0; oi < e->ops.size() && oi < e->fused_away.size(); ++oi)
+        if (e->fused_away[oi] && e->ops[oi].dst == ti)
+            return fail(TS2D_ERR_INVALID, "tensor '%s' was not materialised by the last run: the transposed conv is composed into the next block "
+                        "(set TS2D_UPC=0 before creating the engine to run it as its own kernel)", name);
     const int B = e->lastB, h = e->lastH >> t.level, w = e->lastW >> t.level, C = t.C;
     dims[0] = B; dims[1] = C; dims[2] = h; dims[3] = w;
     const size_t n = (size_t)B * C * h * w;

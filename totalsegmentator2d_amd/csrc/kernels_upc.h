@@ -1,0 +1,354 @@
+// Decoder block entry without the upsampled tensor (SURVEY K5 + K6: ConvTranspose2d 2x2 stride 2, torch.cat((up, skip), 1), Conv2d
+// 3x3): the transposed conv and the "up" half of the 3x3 conv are COMPOSED into one convolution over the coarse tensor.
+//
+//   up[cu][2i+a][2j+b] = sum_cb x[cb][i][j] WT[cb][cu][a][b] + bT[cu]        (no norm / activation follows the transposed conv)
+//   y[co][Y][X]        = sum_{ky,kx} sum_cu W3[co][cu][ky][kx] up[cu][Y+ky-1][X+kx-1] + (skip half) + b3[co]
+// For an output pixel of parity (A, B) = (Y & 1, X & 1) the three taps of a row/column land on TWO coarse pixels, so the up half is
+// a 2x2 convolution over the coarse image with parity-specific weights
+//   Weff[A][B][dI][dJ][co][cb] = sum_{ky in S(A,dI)} sum_{kx in S(B,dJ)} sum_cu W3[co][cu][ky][kx] WT[cb][cu][a(A,ky)][b(B,kx)]
+// (composed on the host in fp64, then split into fp16 hi + lo like every weight).  K per output = 4 Cb instead of 9 Cu, the
+// upsampled tensor is never written or read (at level 0: 67 MB per slice of HBM traffic), and the ConvTranspose2d launch is
+// gone.  Zero padding of `up` = zero padding of the coarse patch (an out-of-image up pixel maps to an out-of-image coarse pixel);
+// the transposed conv's bias reaches an output through the in-image taps only, which gives nine bias variants per channel
+// (top / middle / bottom x left / middle / right), also prepared on the host.
+//
+// Kernel: 256 threads, 8 x 32 output pixels x BN channels, 2-3 workgroups per CU.  The M dimension is grouped BY PARITY: wave w
+// owns parity class (A, B) = (w >> 1, w & 1), its two 32-row MFMA tiles are the 4 x 16 coarse positions (I, J) of the tile, i.e.
+// output pixels (2I + A, 2J + B).  Phase 1 walks the coarse channels in chunks of 16 (4 "taps" (dI, dJ) per wave: 4 x 12 MFMAs
+// for BN = 64), phase 2 the skip channels with the ordinary 9 taps (patch columns stored even-first / odd-second so that the
+// stride-2 pixel walk of a fragment is a walk over consecutive LDS slots).  k-group-major planes as in kernels_f16x3_p.h; row
+// pitches (32 / 40 slots) chosen so that the two 16-lane runs of a fragment read fall on disjoint slot residues.
+#pragma once
+#include "kernels_f16x3_one.h"
+
+namespace ts2d {
+
+struct UpcArgs {
+    const float* xc; const float* scc; const float* shc; int Cb;      // coarse tensor [B, H/2, W/2, Cb] + its scale / shift
+    const float* xs; const float* scs; const float* shs; int Cs;      // skip tensor [B, H, W, Cs] + its scale / shift
+    const void* wc;        // composed weights [chunk Cb/16][column tile][16 = (A,B,dI,dJ)][hi,lo][h][column][8 halves]
+    const void* wk;        // skip-half 3x3 weights [chunk Cs/16][column tile][9 taps][hi,lo][h][column][8 halves]
+    const float* bvar;     // [9 = (ry, rx)][Cout]: b3 + the transposed conv's bias through the in-image taps
+    const float* oscale;   // 1 / (common power-of-two pre-scale of wc and wk)
+    float* dst; float* part;
+    int B, H, W, Cout;     // output geometry (H % 8 == 0, W % 32 == 0)
+    int tiles_x, tiles_y, n_mtiles, n_ctiles, lg_nct, lg_tx, lg_tpi;
+    float slope;
+};
+
+constexpr int kUcPitch = 32, kUcSlots = 6 * kUcPitch, kUcPlane = kUcSlots * 16;        // coarse patch: 6 rows x 18 (pitch 32) slots
+constexpr int kUsPitch = 40, kUsSlots = 10 * kUsPitch, kUsPlane = kUsSlots * 16;       // skip patch: 10 rows x (17 even | 17 odd at +20)
+
+template <int BN>
+__global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const UpcArgs a) {
+    constexpr int NT = BN / 32;
+    constexpr int WT1 = 4 * BN * 16;                        // bytes per "tap": [part][h][column]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = bid >> 3;
+    const int qm = q8 >> a.lg_nct;
+    const int mtile = qm * 8 + xcd;
+    const int ctile = q8 - qm * a.n_ctiles;
+    if (mtile >= a.n_mtiles) return;
+    const int n0col = ctile * BN;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int nimg0 = mtile >> a.lg_tpi, tin = mtile - nimg0 * tpi;
+    const int tyi = tin >> a.lg_tx, txi = tin - tyi * a.tiles_x;
+    const int ty0 = tyi << 3, tx0 = txi << 5;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), pA = w >> 1, pB = w & 1;      // this wave's output parity
+    const int r = lane & 31, h = lane >> 5;
+    const int octi = (lane >> 3) & 1, oct = octi * 8;
+
+    // LDS: phase 1 [coarse planes 4 x kUcPlane | weights W1]; phase 2 [skip planes 4 x kUsPlane | weights W2] (same memory)
+    unsigned char* sB1 = smem8 + 4 * kUcPlane;
+    unsigned char* sB2 = smem8 + 4 * kUsPlane;
+
+    f32x16 acc_t[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
+
+    // =================================================================================== phase 1: composed up half (coarse tensor)
+    {
+        const int Hc = a.H >> 1, Wc = a.W >> 1;
+        // staging: one unit per thread: slot = 32 w + (lane & 7) + 8 (lane >> 4) of the 6 x 18 patch (row-major, 108 pixels), octet
+        const int pp = 32 * w + (lane & 7) + 8 * (lane >> 4);
+        const int py = pp / 18, px = pp - py * 18;
+        const int iy = (ty0 >> 1) - 1 + py, ix = (tx0 >> 1) - 1 + px;
+        const int lw = octi * kUcPlane + (py * kUcPitch + px) * 16;
+        unsigned vo = 0x80000000u;
+        if (pp < 108) {
+            if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) vo = (unsigned)(((iy * Wc + ix) * a.Cb + oct) * 4);
+            else { *reinterpret_cast<uint4*>(smem8 + lw) = uint4{0u, 0u, 0u, 0u};
+                   *reinterpret_cast<uint4*>(smem8 + lw + 2 * kUcPlane) = uint4{0u, 0u, 0u, 0u}; }
+        }
+        const size_t img_px = (size_t)Hc * Wc;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xc) + (size_t)nimg0 * img_px * a.Cb, 0, (int)(img_px * a.Cb * 4), 0x00020000);
+        const int nch = a.Cb / 16;
+        u32x4 pv0, pv1;
+        auto prefetch = [&](int ch) {
+            pv0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, ch * 64, 0);
+            pv1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16, ch * 64, 0);
+        };
+        prefetch(0);
+        // fragments: M-tile row r = coarse position (I = 2 mt + (r >> 4), J = r & 15); tap (dI, dJ) reads coarse patch pixel
+        // (I + pA + dI, J + pB + dJ)
+        const int abase = h * kUcPlane + (((r >> 4) + pA) * kUcPitch + (r & 15) + pB) * 16;      // + mt * 2 * pitch * 16 + (dI * pitch + dJ) * 16 + part * 2 * Plane
+        const int bbase = 4 * kUcPlane + (w * 4) * WT1 + h * BN * 16 + r * 16;                     // + tap * WT1 + part * 2 * BN * 16 + nt * 512
+        for (int ch = 0; ch < nch; ++ch) {
+            __syncthreads();
+            f32x4 nsa = f32x4{1.f, 1.f, 1.f, 1.f}, nsb = nsa, nta = f32x4{0.f, 0.f, 0.f, 0.f}, ntb = nta;
+            const bool normed = a.scc != nullptr;
+            if (normed) {
+                const float* ps = a.scc + (size_t)nimg0 * a.Cb + ch * 16 + oct; const float* pt = a.shc + (size_t)nimg0 * a.Cb + ch * 16 + oct;
+                nsa = *reinterpret_cast<const f32x4*>(ps); nsb = *reinterpret_cast<const f32x4*>(ps + 4);
+                nta = *reinterpret_cast<const f32x4*>(pt); ntb = *reinterpret_cast<const f32x4*>(pt + 4);
+            }
+            // weights: 16 taps x 4 BN slots, linear copy (named registers)
+            constexpr int WU = 16 * BN * 4, WIT = WU / kBlock;       // 16 (BN = 64) or 8 (BN = 32) per thread
+            const uint4* wsrc = reinterpret_cast<const uint4*>(a.wc) + ((size_t)ch * a.n_ctiles + ctile) * WU;
+            uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;
+#define TS2D_WL(K, R) { if (K < WIT) R = wsrc[tid + K * kBlock]; }
+            TS2D_WL(0, w0) TS2D_WL(1, w1) TS2D_WL(2, w2) TS2D_WL(3, w3) TS2D_WL(4, w4) TS2D_WL(5, w5) TS2D_WL(6, w6) TS2D_WL(7, w7)
+            TS2D_WL(8, w8) TS2D_WL(9, w9) TS2D_WL(10, w10) TS2D_WL(11, w11) TS2D_WL(12, w12) TS2D_WL(13, w13) TS2D_WL(14, w14) TS2D_WL(15, w15)
+#undef TS2D_WL
+            if (vo != 0x80000000u) {
+                f32x4 va = __builtin_bit_cast(f32x4, pv0), vb = __builtin_bit_cast(f32x4, pv1);
+                if (normed) {
+                    va = va * nsa + nta; vb = vb * nsb + ntb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { va[e] = fmaxf(va[e], va[e] * a.slope); vb[e] = fmaxf(vb[e], vb[e] * a.slope); }
+                }
+                uint4 hi, lo;
+                split_hi_lo_8(va, vb, hi, lo);
+                *reinterpret_cast<uint4*>(smem8 + lw) = hi;
+                *reinterpret_cast<uint4*>(smem8 + lw + 2 * kUcPlane) = lo;
+            }
+#define TS2D_WS(K, R) { if (K < WIT) *reinterpret_cast<uint4*>(sB1 + (tid + K * kBlock) * 16) = R; }
+            TS2D_WS(0, w0) TS2D_WS(1, w1) TS2D_WS(2, w2) TS2D_WS(3, w3) TS2D_WS(4, w4) TS2D_WS(5, w5) TS2D_WS(6, w6) TS2D_WS(7, w7)
+            TS2D_WS(8, w8) TS2D_WS(9, w9) TS2D_WS(10, w10) TS2D_WS(11, w11) TS2D_WS(12, w12) TS2D_WS(13, w13) TS2D_WS(14, w14) TS2D_WS(15, w15)
+#undef TS2D_WS
+            __syncthreads();
+            if (ch + 1 < nch) prefetch(ch + 1);
+            f32x16 acc_c[2][NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc_c[mt][nt][i] = 0.f;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                const int toff = ((tap >> 1) * kUcPitch + (tap & 1)) * 16;
+                half8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    ah[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff);
+                    al[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff + 2 * kUcPlane);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bh[nt] = *reinterpret_cast<const half8*>(smem8 + bbase + tap * WT1 + nt * 512);
+                    bl[nt] = *reinterpret_cast<const half8*>(smem8 + bbase + tap * WT1 + nt * 512 + 2 * BN * 16);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
+        }
+    }
+
+    // =================================================================================== phase 2: skip half (ordinary 3x3 taps)
+    {
+        __syncthreads();                                    // phase-1 LDS reads are done: the memory is re-laid out
+        constexpr int MAXU = 3;
+        unsigned vo[MAXU];
+        int lw[MAXU];
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) {
+            // unit enumeration: patch row, then its 17 even columns, then its 17 odd columns (LDS slots +20)
+            const int q = 32 * (4 * it + w) + (lane & 7) + 8 * (lane >> 4);
+            const int py = q / 34, rem = q - py * 34;
+            const int half = rem >= 17 ? 1 : 0, idx = rem - 17 * half, px = 2 * idx + half;
+            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+            unsigned v = 0x80000000u;
+            lw[it] = octi * kUsPlane + (py * kUsPitch + 20 * half + idx) * 16;
+            if (q < 340) {
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = (unsigned)(((iy * a.W + ix) * a.Cs + oct) * 4);
+                else { *reinterpret_cast<uint4*>(smem8 + lw[it]) = uint4{0u, 0u, 0u, 0u};
+                       *reinterpret_cast<uint4*>(smem8 + lw[it] + 2 * kUsPlane) = uint4{0u, 0u, 0u, 0u}; }
+            }
+            vo[it] = v;
+        }
+        const size_t img_px = (size_t)a.H * a.W;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xs) + (size_t)nimg0 * img_px * a.Cs, 0, (int)(img_px * a.Cs * 4), 0x00020000);
+        const int nch = a.Cs / 16;
+        u32x4 pv[MAXU][2];
+        auto prefetch = [&](int ch) {
+#pragma unroll
+            for (int it = 0; it < MAXU; ++it) {
+                pv[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[it], ch * 64, 0);
+                pv[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[it] + 16, ch * 64, 0);
+            }
+        };
+        prefetch(0);
+        // fragments: row r = (I = 2 mt + (r >> 4), J = r & 15) -> output pixel (2I + pA, 2J + pB); tap (ky, kx) reads patch pixel
+        // (2I + pA + ky, 2J + pB + kx): patch row 2I + pA + ky, column parity (pB + kx) & 1, index J + ((pB + kx) >> 1)
+        const int abase = h * kUsPlane + ((2 * (r >> 4) + pA) * kUsPitch + (r & 15)) * 16;       // + mt * 4 * pitch * 16 + tap offset + part * 2 * Plane
+        const int bbase = 4 * kUsPlane + h * BN * 16 + r * 16;
+        int tofs[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) tofs[kx] = ((((pB + kx) & 1) ? 20 : 0) + ((pB + kx) >> 1)) * 16;
+        for (int ch = 0; ch < nch; ++ch) {
+            __syncthreads();
+            f32x4 nsa = f32x4{1.f, 1.f, 1.f, 1.f}, nsb = nsa, nta = f32x4{0.f, 0.f, 0.f, 0.f}, ntb = nta;
+            const bool normed = a.scs != nullptr;
+            if (normed) {
+                const float* ps = a.scs + (size_t)nimg0 * a.Cs + ch * 16 + oct; const float* pt = a.shs + (size_t)nimg0 * a.Cs + ch * 16 + oct;
+                nsa = *reinterpret_cast<const f32x4*>(ps); nsb = *reinterpret_cast<const f32x4*>(ps + 4);
+                nta = *reinterpret_cast<const f32x4*>(pt); ntb = *reinterpret_cast<const f32x4*>(pt + 4);
+            }
+            constexpr int WU = 9 * BN * 4, WIT = (WU + kBlock - 1) / kBlock;
+            const uint4* wsrc = reinterpret_cast<const uint4*>(a.wk) + ((size_t)ch * a.n_ctiles + ctile) * WU;
+            uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8;
+#define TS2D_WL(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU)) R = wsrc[idx]; }
+            TS2D_WL(0, w0) TS2D_WL(1, w1) TS2D_WL(2, w2) TS2D_WL(3, w3) TS2D_WL(4, w4) TS2D_WL(5, w5) TS2D_WL(6, w6) TS2D_WL(7, w7) TS2D_WL(8, w8)
+#undef TS2D_WL
+#pragma unroll
+            for (int it = 0; it < MAXU; ++it) {
+                if (vo[it] != 0x80000000u) {
+                    f32x4 va = __builtin_bit_cast(f32x4, pv[it][0]), vb = __builtin_bit_cast(f32x4, pv[it][1]);
+                    if (normed) {
+                        va = va * nsa + nta; vb = vb * nsb + ntb;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { va[e] = fmaxf(va[e], va[e] * a.slope); vb[e] = fmaxf(vb[e], vb[e] * a.slope); }
+                    }
+                    uint4 hi, lo;
+                    split_hi_lo_8(va, vb, hi, lo);
+                    *reinterpret_cast<uint4*>(smem8 + lw[it]) = hi;
+                    *reinterpret_cast<uint4*>(smem8 + lw[it] + 2 * kUsPlane) = lo;
+                }
+            }
+#define TS2D_WS(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU)) *reinterpret_cast<uint4*>(sB2 + idx * 16) = R; }
+            TS2D_WS(0, w0) TS2D_WS(1, w1) TS2D_WS(2, w2) TS2D_WS(3, w3) TS2D_WS(4, w4) TS2D_WS(5, w5) TS2D_WS(6, w6) TS2D_WS(7, w7) TS2D_WS(8, w8)
+#undef TS2D_WS
+            __syncthreads();
+            if (ch + 1 < nch) prefetch(ch + 1);
+            f32x16 acc_c[2][NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc_c[mt][nt][i] = 0.f;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const int toff = ky * kUsPitch * 16 + tofs[kx];
+                half8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    ah[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 4 * kUsPitch * 16 + toff);
+                    al[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 4 * kUsPitch * 16 + toff + 2 * kUsPlane);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bh[nt] = *reinterpret_cast<const half8*>(smem8 + bbase + tap * WT1 + nt * 512);
+                    bl[nt] = *reinterpret_cast<const half8*>(smem8 + bbase + tap * WT1 + nt * 512 + 2 * BN * 16);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
+        }
+    }
+
+    // =================================================================================== epilogue: scatter by parity, statistics
+    // C/D map: column = lane & 31 (channel), row rho = (i & 3) + 8 (i >> 2) + 4 h -> (I = 2 mt + (rho >> 4), J = rho & 15)
+    const float oscale = *a.oscale;
+    const size_t img_el = (size_t)a.H * a.W * a.Cout;
+    const auto rsd = __builtin_amdgcn_make_buffer_rsrc(a.dst + (size_t)nimg0 * img_el, 0, (int)(img_el * 4), 0x00020000);
+    const bool edge = tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1;       // wave-uniform
+    float st_s[NT], st_q[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = n0col + nt * 32 + r;
+        const float bmid = a.bvar[4 * a.Cout + co];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            // lane part: J offset 4 h -> X offset 8 h pixels
+            const unsigned voff = (unsigned)((((ty0 + 4 * mt + pA) * a.W + tx0 + 8 * h + pB) * a.Cout + co) * 4);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int dI = i >> 3, dJ = (i & 3) + 8 * ((i >> 2) & 1);          // rho = (i&3) + 8 (i>>2): rho >> 4 = i >> 3, rho & 15 as here (+ 4 h)
+                const unsigned soff = (unsigned)(((2 * dI * a.W + 2 * dJ) * a.Cout) * 4);      // scalar
+                float bv = bmid;
+                if (edge) {
+                    const int Y = ty0 + 4 * mt + pA + 2 * dI, X = tx0 + pB + 2 * (dJ + 4 * h);
+                    const int ry = Y == 0 ? 0 : (Y == a.H - 1 ? 2 : 1), rx = X == 0 ? 0 : (X == a.W - 1 ? 2 : 1);
+                    bv = a.bvar[(ry * 3 + rx) * a.Cout + co];
+                }
+                const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
+                s += v; q = __builtin_fmaf(v, v, q);
+            }
+        }
+        st_s[nt] = s; st_q[nt] = q;
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem8);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float s = st_s[nt], q = st_q[nt];
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+        if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
+    }
+    __syncthreads();
+    if (tid < BN) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
+        float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
+        p[0] = s; p[1] = q;
+    }
+}
+
+}  // namespace ts2d

@@ -208,6 +208,17 @@ class Engine:
         shp = tuple(int(d) for d in dims)
         return out[:int(np.prod(shp))].reshape(shp).copy()
 
+    def materialised(self, name: str) -> bool:
+        """Test accessor: False if the last forward composed the op that produces `name` into its consumer (a transposed conv
+        folded into the next block, ``csrc/kernels_upc.h``), so that the tensor was never written."""
+        try:
+            self.debug_tensor(name)
+            return True
+        except RuntimeError as ex:
+            if 'not materialised' in str(ex):
+                return False
+            raise
+
     def device_bytes(self) -> int:
         return int(self.lib.ts2d_engine_device_bytes(self._h))
 
