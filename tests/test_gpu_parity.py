@@ -235,6 +235,7 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
     monkeypatch.setenv('TS2D_RES', '0')                    # (conv3x3_res32, conv3x3s2_v2 and conv3x3_upc sum in another order: compared by value below)
     monkeypatch.setenv('TS2D_S2V2', '0')
     monkeypatch.setenv('TS2D_UPC', '0')
+    monkeypatch.setenv('TS2D_Q', '0')                      # (conv3x3_f16x3_q: same conv outputs, statistics summed over other tiles)
     with Engine(arch, blob) as e:
         lg1, _ = e.forward(x, logits=True)
         t1 = {n: e.debug_tensor(n) for n in names}

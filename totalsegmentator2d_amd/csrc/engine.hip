@@ -9,6 +9,7 @@
 #include "kernels_head.h"
 #include "kernels_f16x3_one.h"
 #include "kernels_f16x3_p.h"
+#include "kernels_f16x3_q.h"
 #include "kernels_first.h"
 #include "kernels_res32.h"
 #include "kernels_s2v2.h"
@@ -129,6 +130,7 @@ struct ts2d_engine {
     int wino_min = 0;             // Winograd kernel for stride-1 blocks with at least this many input channels (TS2D_WINO; 0 = off)
     bool use_p = true;            // plane-layout stride-1 kernel (TS2D_P=0 falls back to conv3x3_f16x3_one)
     bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
+    bool use_q = true;            // 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (TS2D_Q=0 falls back to conv3x3_f16x3_p)
     bool use_upc = true;          // decoder c0 blocks composed with their transposed conv (TS2D_UPC=0 falls back to two kernels)
     std::vector<char> fused_away; // per op of the last run: 1 = its output tensor was not materialised (composed into the next op)
     bool use_res = true;          // resident-weight kernel of the 32 -> 32 blocks (TS2D_RES=0 falls back)
@@ -1085,7 +1087,26 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
             const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32;
             const bool one_s2 = split && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;
-            if (one && e->use_p && bn == 64 && Ht % 8 == 0 && Wt % 32 == 0 && g.lgTH == 3 && g.lgTW == 5) {
+            const bool qtile = one && e->use_q && bn == 64 && ct_total(op) >= 128 && Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr &&      // (>= 8 chunks: measured)
+                               (op.skip < 0 || e->tensors[op.skip].scale != nullptr) && lg_exact(Wt / 32) >= 0 && lg_exact((Wt / 32) * (Ht / 16)) >= 0;
+            if (qtile) {
+                // complete 16 x 32 tiles x 64 columns, normalised sources: one 512-thread workgroup per CU, patch and weights
+                // double-buffered (weights by LDS-DMA), one barrier per chunk
+                ca.wph = wts + op.dev_wp;
+                ca.tiles_x = Wt / 32; ca.tiles_y = Ht / 16; ca.n_mtiles = B * ca.tiles_x * ca.tiles_y;
+                ca.lg_tx = lg_exact(ca.tiles_x); ca.lg_tpi = lg_exact(ca.tiles_x * ca.tiles_y);
+                const int gridq = (ca.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
+#define TS2D_Q_LAUNCH(D_) do { static std::atomic<uint64_t> doneq_{0}; \
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_q<D_>), doneq_)); \
+                    hipLaunchKernelGGL(conv3x3_f16x3_q<D_>, dim3(gridq), dim3(kQThreads), kQLds, st, ca); } while (0)
+                switch (e->dbg) {       // (TS2D_DBG: timing ablations, diagnostic runs only)
+                    case 1: TS2D_Q_LAUNCH(1); break; case 2: TS2D_Q_LAUNCH(2); break; case 4: TS2D_Q_LAUNCH(4); break;
+                    case 8: TS2D_Q_LAUNCH(8); break; case 16: TS2D_Q_LAUNCH(16); break; case 32: TS2D_Q_LAUNCH(32); break; case 64: TS2D_Q_LAUNCH(64); break; case 128: TS2D_Q_LAUNCH(128); break; case 14: TS2D_Q_LAUNCH(14); break; case 15: TS2D_Q_LAUNCH(15); break;
+                    default: TS2D_Q_LAUNCH(0); break;
+                }
+#undef TS2D_Q_LAUNCH
+                le = hipGetLastError();
+            } else if (one && e->use_p && bn == 64 && Ht % 8 == 0 && Wt % 32 == 0 && g.lgTH == 3 && g.lgTW == 5) {
                 // complete 8 x 32 tiles x 64 columns: plane layout (conflict-free LDS; same speed as the record layout - measured;
                 // the 32-column variant lost its third workgroup per CU to registers and stays on conv3x3_f16x3_one)
                 ca.wph = wts + op.dev_wp;
@@ -1115,7 +1136,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                     else hipLaunchKernelGGL(splitk_reduce_stats<float>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, ksplit, ca.kslice_stride,
                                             wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.data, dst.scale, dst.shift);
                 } else if (fused) {
-                    launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
+                    launch_finalize(B, op.cout, st, e->d_part, qtile ? ca.tiles_x * ca.tiles_y : g.tiles_x * g.tiles_y,
                                        op.cout, B, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 } else {
                     launch_stats_direct(f16, B, op.cout, HW, dst.data, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift, st);
@@ -1185,6 +1206,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_RES")) e->use_res = getenv("TS2D_RES")[0] == '1';
         if (getenv("TS2D_S2V2")) e->use_s2v2 = getenv("TS2D_S2V2")[0] == '1';
         if (getenv("TS2D_P")) e->use_p = getenv("TS2D_P")[0] == '1';
+        if (getenv("TS2D_Q")) e->use_q = getenv("TS2D_Q")[0] == '1';
         if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
         if (getenv("TS2D_WINO")) e->wino_min = atoi(getenv("TS2D_WINO"));
