@@ -262,7 +262,7 @@ def main():
     profile = not args.no_profile and rank == 0
     if profile:
         engine.set_profiling(True)
-    op_ms = {}
+    op_ms, op_kernels = {}, {}
     torch.cuda.synchronize(dev)
     if multi:
         dist.barrier()
@@ -273,6 +273,7 @@ def main():
         if profile:                                                        # HIP events on the launch stream, read per step
             for k, v in engine.op_times().items():
                 op_ms[k] = op_ms.get(k, 0.0) + v
+            op_kernels = engine.op_kernels()
     torch.cuda.synchronize(dev)
     if multi:
         dist.barrier()
@@ -317,34 +318,50 @@ def main():
             conv_ms = sum(ms[k] for k in per if k in ms)
             conv_flops = sum(per.values()) * B
             peak = {'split': PEAK_F16_MFMA_TFLOPS / 3.0, 'exact': PEAK_FP32_MFMA_TFLOPS, 'f16': PEAK_F16_MFMA_TFLOPS}[args.precision]
-            # (b) the DOMINANT KERNEL: the 64-column stride-1 kernel of levels 1-4 (complete 8 x 32 tiles; 12 launches/step) - MFMA-bound
-            dom = [n for n, (o, m) in layer.items() if n in per and o['cout'] >= 64 and (H >> o['level']) >= 32]
-            dom_ms = sum(ms[k] for k in dom if k in ms)
-            dom_flops = sum(per[k] for k in dom) * B
-            achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-            dom_kernel = {'split': 'conv3x3_f16x3_p<64>', 'f16': 'conv3x3_h32<64>', 'exact': 'conv_mfma_f32<9,1,16,64>'}[args.precision]
-            traffic, traffic_stale = None, None
+            # (b) the DOMINANT KERNEL, chosen by measured time: ops grouped by the kernel that served them (ts2d_engine_op_kernel).
+            #     Algorithmic FLOPs of an op = the reference's own arithmetic (2 x MACs of the conv; a composed block
+            #     conv3x3_upc also carries the MACs of the ConvTranspose2d it absorbed, whose own launch no longer exists).
+            alg = {n: 2.0 * m['macs'] for n, (o, m) in layer.items()}
+            groups = {}
+            for n, kname in op_kernels.items():
+                if n.endswith('.stats') or n not in ms or n not in alg:
+                    continue
+                g = groups.setdefault(kname, {'ops': [], 'ms': 0.0, 'flops': 0.0})
+                g['ops'].append(n); g['ms'] += ms[n]; g['flops'] += alg[n] * B
+                if kname.startswith('conv3x3_upc'):
+                    g['flops'] += alg.get(n.replace('.c0', '.up'), 0.0) * B
+            pmc_avg, traffic_stale = {}, None
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(pmc):
                 try:
                     pj = json.load(open(pmc))
                     traffic_stale = pj.get('csrc_hash') != csrc_hash()          # measured on other kernel sources: do not report it
-                    traffic = None if traffic_stale else pj.get('hbm_bytes_per_launch_avg', {}).get(dom_kernel)
+                    pmc_avg = {} if traffic_stale else pj.get('hbm_bytes_per_launch_avg', {})
                 except Exception:
-                    traffic = None
-            all3 = {o['name'] for o in prog if o['op'] == OP_CONV3X3}
+                    pmc_avg = {}
             pipe = MEASURED_F16_PIPE_TFLOPS / (3.0 if split else 1.0)
+            table = []
+            for kname, g in sorted(groups.items(), key=lambda kv: -kv[1]['ms']):
+                tf = g['flops'] / (g['ms'] * 1e-3) / 1e12
+                table.append({'kernel': kname, 'launches_per_step': len(g['ops']), 'ms_per_step': round(g['ms'], 3),
+                              'share_of_step': round(g['ms'] / ms_per_step, 4), 'algorithmic_tflops': round(tf, 2),
+                              'frac_of_peak': round(tf / peak, 4), 'hbm_bytes_per_launch': pmc_avg.get(kname), 'ops': sorted(g['ops'])})
+            dom_kernel, dg = max(groups.items(), key=lambda kv: kv[1]['ms'])
+            dom, dom_ms, dom_flops = dg['ops'], dg['ms'], dg['flops']
+            achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+            traffic = pmc_avg.get(dom_kernel)
+            all3 = {o['name'] for o in prog if o['op'] == OP_CONV3X3}
             out['roofline'] = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                                'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_stale': traffic_stale,
-                               'kernel': f'{dom_kernel} ({len(dom)} launches/step: stride-1 3x3 blocks of levels 1-4)',
+                               'kernel': f'{dom_kernel} ({len(dom)} launches/step: {", ".join(sorted(dom))})',
                                'peak_note': ('dense fp16 MFMA 2500 TFLOP/s / 3 products per MAC' if split else
                                              ('dense fp16 MFMA' if args.precision == 'f16' else 'fp32 MFMA 32x32x2')),
-                               # profiles/r01_mfma_coissue_probe.txt, scripts/probes/mfma_shape_probe.hip: a bare v_mfma_f32_32x32x16_f16
-                               # stream on every SIMD runs at 20.5-21 ns per MFMA (= 32 cycles at the ~1.5 GHz held under matrix load)
+                               # scripts/probes/mfma_shape_probe.hip: v_mfma_f32_32x32x16_f16 on every SIMD, operands from registers, random data
                                'frac_of_measured_matrix_pipe_rate': round(achieved / pipe, 4) if args.precision in ('split', 'f16') else None,
                                'algorithmic_flop_per_launch_avg': round(dom_flops / len(dom)),
                                'kernel_ms_per_launch_avg': round(dom_ms / len(dom), 4),
                                'kernel_ms_per_step': round(dom_ms, 3), 'kernel_share_of_step': round(dom_ms / ms_per_step, 4)}
+            out['roofline_kernels'] = table
             fam = conv_flops / (conv_ms * 1e-3) / 1e12
             out['roofline_stride1_family'] = {'bound': 'mfma', 'achieved': round(fam, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                                               'frac': round(fam / peak, 4), 'launches_per_step': len(per), 'ms_per_step': round(conv_ms, 3),
@@ -358,6 +375,8 @@ def main():
                     cin = o['cin'] + o.get('cin_skip', 0)
                     px_in = (H * W) if o['op'] != 1 else (H * W) // 4          # transposed conv reads the level below
                     rd = px_in * cin * (4 if o['src'] == 'input' else esz)
+                    if op_kernels.get(n, '').startswith('conv3x3_upc'):      # composed block: reads the COARSE tensor instead of `up`
+                        rd = ((H * W) // 4 * layer[n.replace('.c0', '.up')][0]['cin'] + H * W * o['cin_skip']) * esz
                     wr = H * W * o['cout'] * (4 if n == 'head' else esz)
                     l0[n] = (rd + wr) * B
             l0_ms = sum(ms[k] for k in l0)

@@ -166,6 +166,9 @@ int ts2d_engine_reserve(ts2d_engine* e, int B, int H, int W);
 int ts2d_engine_set_profiling(ts2d_engine* e, int enable);
 int ts2d_engine_num_ops(ts2d_engine* e);
 const char* ts2d_engine_op_name(ts2d_engine* e, int op);
+/* The kernel that served entry `op` of the last profiled forward ("conv3x3_f16x3_q", "conv3x3_upc<64>", "finalize_stats", ...):
+ * the dispatch depends on precision mode, channel counts and tile geometry, bench.py groups its roofline blocks by this. */
+const char* ts2d_engine_op_kernel(ts2d_engine* e, int op);
 int ts2d_engine_op_times(ts2d_engine* e, float* ms, int n_ops);
 
 /* Test/debug accessor (not on the product path): copies activation tensor `name` ("enc0.c1", "dec3.up", ... - the

@@ -23,10 +23,14 @@ def load(path, counter):
 
 
 def short(k):
+    """rocprof kernel name -> the label ts2d_engine_op_kernel reports (variants that share a label are summed)."""
     k = k.replace('void ', '').replace('ts2d::', '')
     k = re.sub(r'\(.*$', '', k)
-    m = re.match(r'(conv3x3_f16x3_p|conv3x3_f16x3_one|conv3x3_h32)<(\d+)', k)
-    return f'{m.group(1)}<{m.group(2)}>' if m else k
+    m = re.match(r'([A-Za-z0-9_]+)(?:<(\d+))?', k)
+    base, first = m.group(1), m.group(2)
+    if base in ('conv3x3_f16x3_p', 'conv3x3_f16x3_one', 'conv3x3_h32', 'conv3x3_upc', 'conv3x3s2_v2') and first:
+        return f'{base}<{first}>'
+    return {'head_mfma32': 'head', 'head_1x1': 'head', 'finalize_stats_t': 'finalize_stats', 'convT2x2_f16x3_one': 'convT2x2_f16x3'}.get(base, base)
 
 
 def main():
@@ -34,14 +38,16 @@ def main():
     fetch, nf = load(sys.argv[1], 'FETCH_SIZE')
     write, nw = load(sys.argv[2], 'WRITE_SIZE')
     passes = int(sys.argv[3])
+    agg = {}
+    for k in set(fetch) | set(write):
+        g = agg.setdefault(short(k), {'disp': 0, 'fb': 0.0, 'wb': 0.0})
+        g['disp'] += int(nf.get(k, nw.get(k, 0))); g['fb'] += fetch.get(k, 0) * 2048; g['wb'] += write.get(k, 0) * 1024
     per, avg = {}, {}
-    for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) * 2048 + write.get(k, 0) * 1024)):
-        disp = int(nf.get(k, nw.get(k, 0)))
-        fb, wb = fetch.get(k, 0) * 2048, write.get(k, 0) * 1024
-        per[short(k)] = {'dispatches': disp, 'launches_per_step': disp / passes, 'fetch_GB_per_step_corrected': round(fb / passes / 1e9, 3),
-                         'write_GB_per_step': round(wb / passes / 1e9, 3)}
-        if disp:
-            avg[short(k)] = int((fb + wb) / disp)
+    for k, g in sorted(agg.items(), key=lambda kv: -(kv[1]['fb'] + kv[1]['wb'])):
+        per[k] = {'dispatches': g['disp'], 'launches_per_step': g['disp'] / passes, 'fetch_GB_per_step_corrected': round(g['fb'] / passes / 1e9, 3),
+                  'write_GB_per_step': round(g['wb'] / passes / 1e9, 3)}
+        if g['disp']:
+            avg[k] = int((g['fb'] + g['wb']) / g['disp'])
     out = {
         'csrc_hash': csrc_hash(),
         'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --no-cpu-baseline --no-other-modes --no-profile, B=64, split mode',

@@ -90,7 +90,7 @@ struct Op {
     size_t dev_wraw = 0;
 };
 
-struct Launch { std::string name; hipEvent_t e0 = nullptr, e1 = nullptr; };
+struct Launch { std::string name, kernel; hipEvent_t e0 = nullptr, e1 = nullptr; };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one process may drive engines on several GPUs
 // (include/ts2d_engine.h: handles are independent), so the "already set" state is a bit per device, not one flag per process.
@@ -132,6 +132,7 @@ struct ts2d_engine {
     bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
     bool use_q = true;            // 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (TS2D_Q=0 falls back to conv3x3_f16x3_p)
     bool use_upc = true;          // decoder c0 blocks composed with their transposed conv (TS2D_UPC=0 falls back to two kernels)
+    unsigned long long* d_prof = nullptr;     // TS2D_DBG=256: in-kernel phase counters, 8 per op (diagnostic)
     std::vector<char> fused_away; // per op of the last run: 1 = its output tensor was not materialised (composed into the next op)
     bool use_res = true;          // resident-weight kernel of the 32 -> 32 blocks (TS2D_RES=0 falls back)
     // workspace
@@ -803,8 +804,13 @@ int prof_begin(ts2d_engine* e, const std::string& name, hipStream_t st) {
         e->launches.push_back(l);
     }
     e->launches[e->n_launched].name = name;
+    e->launches[e->n_launched].kernel.clear();
     HIP_TRY(hipEventRecord(e->launches[e->n_launched].e0, st));
     return TS2D_OK;
+}
+// which kernel served the op being profiled (ts2d_engine_op_kernel): called between prof_begin and prof_end
+void prof_kernel(ts2d_engine* e, const std::string& kernel) {
+    if (e->profiling && e->n_launched < e->launches.size()) e->launches[e->n_launched].kernel = kernel;
 }
 int prof_end(ts2d_engine* e, hipStream_t st) {
     if (!e->profiling) return TS2D_OK;
@@ -861,6 +867,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
     if (!e->ops[0].first_direct) {   // boundary layout change NCHW -> NHWC (channels zero-padded to 8); > 4 input channels only
         const long long total = (long long)B * H * W;
         TRY(prof_begin(e, "input.nhwc", st));
+        prof_kernel(e, "nchw_to_nhwc_pad");
         hipLaunchKernelGGL(nchw_to_nhwc_pad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                            d_in, a.input_channels, H * W, total, e->cin_pad, e->tensors[0].data);
         HIP_TRY(hipGetLastError());
@@ -881,7 +888,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             fa.n_mtiles = g.n_mtiles; fa.PH = g.PH; fa.PW = g.PW;
             const int kp = (op.cin + 1) / 2, nt = op.cout / 32, P = (g.PH * g.PW) << g.lgNIMG;
             const size_t smem = std::max((size_t)P * (2 * kp + 1) * sizeof(float), (size_t)4 * op.cout * 2 * sizeof(float));
-            TRY(prof_begin(e, op.name, st));
+            TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_first");
 #define TS2D_FIRST(NT_, KP_) do { if (f16) hipLaunchKernelGGL((conv3x3_first<NT_, KP_, _Float16>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa); \
                                   else hipLaunchKernelGGL((conv3x3_first<NT_, KP_, float>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa); } while (0)
             if (nt == 1 && kp == 1) TS2D_FIRST(1, 1);
@@ -891,7 +898,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             else return fail(TS2D_ERR_INVALID, "first block: unsupported Cout %d / Cin %d", op.cout, op.cin);
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
-            TRY(prof_begin(e, op.name + ".stats", st));
+            TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
             if (fused)
                 launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
                                    op.cout, B, H * W, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
@@ -919,9 +926,10 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             ua.tiles_x = Wt / 32; ua.tiles_y = Ht / 8; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y; ua.n_ctiles = op.cout / bn;
             ua.lg_nct = ilog2(ua.n_ctiles); ua.lg_tx = ilog2(ua.tiles_x); ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
             ua.slope = a.leaky_slope;
+            ua.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 8 * oi : nullptr;
             const int grid = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
-            const size_t smem_u = std::max((size_t)4 * kUcPlane + (size_t)16 * 4 * bn * 16, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
-            TRY(prof_begin(e, op.name, st));
+            const size_t smem_u = std::max((size_t)4 * kUcPlane, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
+            TRY(prof_begin(e, op.name, st)); prof_kernel(e, bn == 64 ? "conv3x3_upc<64>" : "conv3x3_upc<32>");
             if (bn == 64) {
                 static std::atomic<uint64_t> done64{0};
                 HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<64>), done64));
@@ -933,7 +941,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             }
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
-            TRY(prof_begin(e, op.name + ".stats", st));
+            TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
             launch_finalize(B, op.cout, st, e->d_part, ua.tiles_x * ua.tiles_y,
                                op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
             HIP_TRY(hipGetLastError());
@@ -972,7 +980,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 ca.wph = wts + op.dev_wu; ca.oscale = wts + op.dev_wus; ca.part = e->d_part;
                 // (grid: 8 XCD lanes x enough rows for either block map of the kernel; surplus blocks return at once)
                 const int gridw = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
-                TRY(prof_begin(e, op.name, st));
+                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_wino");
                 {
                     static std::atomic<uint64_t> donew{0};
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_wino), donew));
@@ -980,7 +988,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 }
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
-                TRY(prof_begin(e, op.name + ".stats", st));
+                TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
                 launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
                                    op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 HIP_TRY(hipGetLastError());
@@ -996,7 +1004,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 const int grid2 = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
                 const int npp = f16 ? 1 : 2;
                 const size_t smem2 = (size_t)npp * 2 * kS2Plane + (size_t)9 * npp * 2 * op.bn2 * 16;
-                TRY(prof_begin(e, op.name, st));
+                TRY(prof_begin(e, op.name, st)); prof_kernel(e, op.bn2 == 128 ? "conv3x3s2_v2<128>" : "conv3x3s2_v2<64>");
 #define TS2D_S2V2_LAUNCH(BN_, ST_, NP_) do { static std::atomic<uint64_t> done_{0}; \
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_>), done_)); \
                     hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } while (0)
@@ -1005,7 +1013,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
 #undef TS2D_S2V2_LAUNCH
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
-                TRY(prof_begin(e, op.name + ".stats", st));
+                TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
                 launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
                                    op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 HIP_TRY(hipGetLastError());
@@ -1026,7 +1034,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 for (int d = 1; d <= tpi_r; ++d) if (tpi_r % d == 0 && ra.n_tiles / d >= want) seg = d;
                 ra.seg = seg;
                 const int nbk = ra.n_tiles / seg;
-                TRY(prof_begin(e, op.name, st));
+                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_res32");
                 if (f16) {
                     static std::atomic<uint64_t> done16{0};
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_res32<_Float16, 1>), done16));
@@ -1038,7 +1046,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 }
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
-                TRY(prof_begin(e, op.name + ".stats", st));
+                TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
                 launch_finalize(B, op.cout, st, e->d_part, tpi_r,
                                    op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 HIP_TRY(hipGetLastError());
@@ -1052,7 +1060,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 const int Pt = 1 << (g.lgTH + g.lgTW + g.lgNIMG);
                 const size_t smem_t = (size_t)2 * Pt * kRec + (size_t)2 * 64 * kRec;
                 const int grid_t = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
-                TRY(prof_begin(e, op.name, st));
+                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "convT2x2_f16x3");
                 const bool t_one = e->use_one && g.lgNIMG == 0 && (size_t)4 * Ht * Wt * op.cout * 4 < ((size_t)1 << 31) &&
                                    ca.lg_tx >= 0 && ca.lg_tpi >= 0 && ca.lg_nct >= 0 && g.lgTH + g.lgTW == 8;
                 if (t_one) {
@@ -1105,31 +1113,32 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                     default: TS2D_Q_LAUNCH(0); break;
                 }
 #undef TS2D_Q_LAUNCH
-                le = hipGetLastError();
+                le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_q");
             } else if (one && e->use_p && bn == 64 && Ht % 8 == 0 && Wt % 32 == 0 && g.lgTH == 3 && g.lgTW == 5) {
                 // complete 8 x 32 tiles x 64 columns: plane layout (conflict-free LDS; same speed as the record layout - measured;
                 // the 32-column variant lost its third workgroup per CU to registers and stays on conv3x3_f16x3_one)
                 ca.wph = wts + op.dev_wp;
                 const size_t smem_p = (size_t)4 * kPPlane + (size_t)9 * 4 * bn * 16;
-                le = launch_p_inst<64, true>(ca, grid, smem_p, st);
+                le = launch_p_inst<64, true>(ca, grid, smem_p, st); prof_kernel(e, "conv3x3_f16x3_p<64>");
             } else if (one) {     // tile inside one image: lean staging path
-                le = launch_one(bn, ca, grid, smem, st);
+                le = launch_one(bn, ca, grid, smem, st); prof_kernel(e, bn == 64 ? "conv3x3_f16x3_one<64>" : "conv3x3_f16x3_one<32>");
             } else if (one_s2) {
-                le = launch_one_s2(f16, bn, ca, grid, smem, st);
+                le = launch_one_s2(f16, bn, ca, grid, smem, st); prof_kernel(e, "conv3x3s2_f16x3_one");
             } else if (h32) {     // fp16 storage: 32-channel chunks, one product
                 ca.wph = wts + op.dev_wh32;
-                le = launch_h32(bn, ca, grid, smem, st);
+                le = launch_h32(bn, ca, grid, smem, st); prof_kernel(e, bn == 64 ? "conv3x3_h32<64>" : "conv3x3_h32<32>");
             } else if (split) {
                 le = stride == 1 ? launch_split(f16, bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, grid, smem, st)
                                  : launch_split_s2(f16, bn, P <= 5 * kBlock ? 5 : 6, ca, grid, smem, st);
+                prof_kernel(e, stride == 1 ? "conv3x3_f16x3" : "conv3x3s2_f16x3");
             } else {
-                le = launch_conv(taps, stride, op.ck, bn, ca, grid, smem, st);
+                le = launch_conv(taps, stride, op.ck, bn, ca, grid, smem, st); prof_kernel(e, conv ? "conv_mfma_f32" : "convT_mfma_f32");
             }
             if (le != hipSuccess) return fail(TS2D_ERR_HIP, "launch of %s failed: %s", op.name.c_str(), hipGetErrorString(le));
             TRY(prof_end(e, st));
             if (conv) {
                 const int HW = Ht * Wt;
-                TRY(prof_begin(e, op.name + ".stats", st));
+                TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
                 if (ksplit > 1) {
                     if (f16) hipLaunchKernelGGL(splitk_reduce_stats<_Float16>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, ksplit, ca.kslice_stride,
                                                 wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, reinterpret_cast<_Float16*>(dst.data), dst.scale, dst.shift);
@@ -1152,6 +1161,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const unsigned grid = (unsigned)((ha.total + 255) / 256);
             const size_t smem = ((size_t)256 * (src.C + 1) + (size_t)op.cout * src.C + op.cout) * sizeof(float);
             TRY(prof_begin(e, op.name, st));
+            prof_kernel(e, "head");
             const bool hm = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT && e->use_one && src.C == 32 && (H * W) % 32 == 0 && W % 32 == 0;
             if (hm) {      // matrix-core head (split / f16 modes)
                 ha.wph = wts + op.dev_wh; ha.oscale = wts + op.dev_ws;
@@ -1185,7 +1195,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
 // ------------------------------------------------------------------------------------------------- C-ABI
 extern "C" {
 
-int ts2d_abi_version(void) { return 2; }
+int ts2d_abi_version(void) { return 3; }
 
 const char* ts2d_last_error(void) { return g_err.c_str(); }
 
@@ -1218,6 +1228,8 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ws_event, hipEventDisableTiming);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&e->d_flags), 2 * sizeof(int));
     if (he == hipSuccess) he = hipMemset(e->d_flags, 0, 2 * sizeof(int));
+    if (he == hipSuccess && e->dbg == 256) he = hipMalloc(reinterpret_cast<void**>(&e->d_prof), 8 * 128 * sizeof(unsigned long long));
+    if (he == hipSuccess && e->d_prof) he = hipMemset(e->d_prof, 0, 8 * 128 * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&e->d_weights), e->weight_floats * sizeof(float));
     if (he != hipSuccess) {
         rc = fail(he == hipErrorOutOfMemory ? TS2D_ERR_NOMEM : TS2D_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he));
@@ -1468,6 +1480,11 @@ int ts2d_engine_set_profiling(ts2d_engine* e, int enable) {
 
 int ts2d_engine_num_ops(ts2d_engine* e) { return e ? (int)e->n_launched : 0; }
 
+const char* ts2d_engine_op_kernel(ts2d_engine* e, int op) {
+    if (!e || op < 0 || (size_t)op >= e->n_launched) return "";
+    return e->launches[op].kernel.c_str();
+}
+
 const char* ts2d_engine_op_name(ts2d_engine* e, int op) {
     if (!e || op < 0 || (size_t)op >= e->n_launched) return "";
     return e->launches[op].name.c_str();
@@ -1475,6 +1492,18 @@ const char* ts2d_engine_op_name(ts2d_engine* e, int op) {
 
 int ts2d_engine_op_times(ts2d_engine* e, float* ms, int n_ops) {
     if (!e || !ms) return fail(TS2D_ERR_INVALID, "ts2d_engine_op_times: null argument");
+    if (e->d_prof) {        // TS2D_DBG=256: print and reset the in-kernel phase counters (cycles of wave 0, averaged over workgroups)
+        std::vector<unsigned long long> hp(8 * 128);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(hp.data(), e->d_prof, hp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(e->d_prof, 0, hp.size() * sizeof(unsigned long long)));
+        for (size_t oi = 0; oi < e->ops.size() && oi < 128; ++oi)
+            if (hp[8 * oi + 7]) {
+                const double n = (double)hp[8 * oi + 7];
+                fprintf(stderr, "[phases] %-8s wgs %6.0f  cycles/wg: p1.stage %8.0f  p1.mfma %8.0f  p2.stage %8.0f  p2.mfma %8.0f  epi.stores %8.0f  epi.bar1 %8.0f  epi.bar2 %8.0f\n",
+                        e->ops[oi].name.c_str(), n, hp[8 * oi] / n, hp[8 * oi + 1] / n, hp[8 * oi + 2] / n, hp[8 * oi + 3] / n, hp[8 * oi + 4] / n, hp[8 * oi + 5] / n, hp[8 * oi + 6] / n);
+            }
+    }
     if ((size_t)n_ops > e->n_launched) n_ops = (int)e->n_launched;
     for (int i = 0; i < n_ops; ++i) {
         HIP_TRY(hipEventSynchronize(e->launches[i].e1));

@@ -11,6 +11,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace ts2d {
 
+// Workgroup barrier for an exchange through LDS: waits for this wave's LDS operations only.  __syncthreads() also fences global
+// memory - after an epilogue's output stores that is s_waitcnt vmcnt(0), the whole HBM write latency of the tile, spent with the
+// matrix pipe idle (in-kernel stamps, gpurun r2 upc_ph: 30-36 % of a level-0 / level-1 workgroup's life).  One asm statement,
+// so that no memory operation moves across it.  (Never between an LDS-DMA and the reads of what it wrote.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+
 constexpr int kBlock = 256;   // threads per workgroup (4 waves, one per SIMD)
 constexpr int kBM = 256;      // output pixels per workgroup tile
 
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
         }
     }
     if (EPI == 0 && a.part != nullptr) {   // fused InstanceNorm partial statistics (host guarantees NIMG == 1)
-        __syncthreads();
+        lds_barrier();
         float* red = smem;                 // [4 waves][BN][2]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
             s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
             if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < BN) {
             float s = 0.f, q = 0.f;
 #pragma unroll

@@ -106,7 +106,7 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
         }
     }
     if (a.part != nullptr) {
-        __syncthreads();
+        lds_barrier();
         float* red = reinterpret_cast<float*>(smem8);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -114,7 +114,7 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
             s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
             if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < BN) {
             float s = 0.f, q = 0.f;
 #pragma unroll
@@ -174,7 +174,7 @@ __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&a
         st_s[nt] = s; st_q[nt] = q;
     }
     if (a.part != nullptr) {
-        __syncthreads();
+        lds_barrier();
         float* red = reinterpret_cast<float*>(smem8);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -182,7 +182,7 @@ __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&a
             s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
             if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < BN) {
             float s = 0.f, q = 0.f;
 #pragma unroll

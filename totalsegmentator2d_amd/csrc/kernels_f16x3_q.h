@@ -162,8 +162,7 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_q(const ConvArgs a
 #pragma unroll
     for (int it = 0; it < MAXU; ++it) convert(it, pbuf0);
     prefetch(nchunks > 1 ? 1 : 0);          // (past the end: the last chunk again - loaded, never used; keeps the loop branch-free)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     const int abase = h * kQPlane + ((2 * w) * kPPW + r) * 16;
     const int bbase = h * BN * 16 + r * 16;
@@ -238,8 +237,7 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_q(const ConvArgs a
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
         // the DMA of chunk ch+1 has landed (only the patch prefetch of chunk ch+2 may stay in flight), this wave's LDS writes are done
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -275,7 +273,7 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_q(const ConvArgs a
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
         if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < BN) {
         float s = 0.f, q = 0.f;
 #pragma unroll

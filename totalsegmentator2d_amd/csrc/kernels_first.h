@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
         st_s[nt] = ss; st_q[nt] = qq;
     }
     if (a.part != nullptr) {
-        __syncthreads();
+        lds_barrier();
         float* red = smem;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
             s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
             if (h == 0) { red[(w * NT * 32 + nt * 32 + r) * 2] = s; red[(w * NT * 32 + nt * 32 + r) * 2 + 1] = q; }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < NT * 32) {
             float s = 0.f, q = 0.f;
 #pragma unroll

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
                     if (NPP == 2) *reinterpret_cast<uint4*>(d + 4 * kResPS) = uint4{0u, 0u, 0u, 0u};
                 }
         }
-        __syncthreads();                                   // patch (and, first tile, the weights) visible to every wave
+        lds_barrier();                                     // patch (and, first tile, the weights) visible to every wave
 
         // ---- next tile of the segment (one row down, or the top of the next column): prefetch its raw patch behind the MFMAs
         int ntx = txi, nty = tyi + 1;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
                 }
             }
         }
-        __syncthreads();                                   // every wave is done with the patch; the scratch is complete
+        lds_barrier();                                     // every wave is done with the patch; the scratch is complete (stores in flight)
         if (tid < 64) {                                    // tile partial (fixed order over the 4 waves)
             const int co = tid >> 1, which = tid & 1, cb = co >> 4, gg = (co >> 2) & 3, i = co & 3;
             float tot = 0.f;

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         }
         st_s[nt] = s; st_q[nt] = q;
     }
-    __syncthreads();                                       // every wave is done with the LDS images
+    lds_barrier();                                         // every wave is done with the LDS images (the output stores stay in flight)
     float* red = reinterpret_cast<float*>(smem8);          // [wm 4][column BN][2]
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
         if (h == 0) { const int c = wn * (BN / 2) + nt * 32 + r; red[(wm * BN + c) * 2] = s; red[(wm * BN + c) * 2 + 1] = q; }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < BN) {
         float s = 0.f, q = 0.f;
 #pragma unroll

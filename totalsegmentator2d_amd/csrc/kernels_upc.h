@@ -12,7 +12,7 @@
 // the transposed conv's bias reaches an output through the in-image taps only, which gives nine bias variants per channel
 // (top / middle / bottom x left / middle / right), also prepared on the host.
 //
-// Kernel: 256 threads, 8 x 32 output pixels x BN channels, 2-3 workgroups per CU.  The M dimension is grouped BY PARITY: wave w
+// Kernel: 256 threads, 8 x 32 output pixels x BN channels, 2-3 workgroups per CU (LDS: the phase-2 image, 62.5 KB at BN = 64).  The M dimension is grouped BY PARITY: wave w
 // owns parity class (A, B) = (w >> 1, w & 1), its two 32-row MFMA tiles are the 4 x 16 coarse positions (I, J) of the tile, i.e.
 // output pixels (2I + A, 2J + B).  Phase 1 walks the coarse channels in chunks of 16 (4 "taps" (dI, dJ) per wave: 4 x 12 MFMAs
 // for BN = 64), phase 2 the skip channels with the ordinary 9 taps (patch columns stored even-first / odd-second so that the
@@ -34,6 +34,7 @@ struct UpcArgs {
     int B, H, W, Cout;     // output geometry (H % 8 == 0, W % 32 == 0)
     int tiles_x, tiles_y, n_mtiles, n_ctiles, lg_nct, lg_tx, lg_tpi;
     float slope;
+    unsigned long long* prof;   // diagnostic: phase cycle counters (6 entries) or nullptr
 };
 
 constexpr int kUcPitch = 32, kUcSlots = 6 * kUcPitch, kUcPlane = kUcSlots * 16;        // coarse patch: 6 rows x 18 (pitch 32) slots
@@ -63,8 +64,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
     const int r = lane & 31, h = lane >> 5;
     const int octi = (lane >> 3) & 1, oct = octi * 8;
 
-    // LDS: phase 1 [coarse planes 4 x kUcPlane | weights W1]; phase 2 [skip planes 4 x kUsPlane | weights W2] (same memory)
-    unsigned char* sB1 = smem8 + 4 * kUcPlane;
+    // LDS: phase 1 [coarse planes 4 x kUcPlane]; phase 2 [skip planes 4 x kUsPlane | weights] (same memory)
     unsigned char* sB2 = smem8 + 4 * kUsPlane;
 
     f32x16 acc_t[2][NT];
@@ -74,6 +74,11 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
+    // in-kernel phase stamps (a.prof != nullptr: diagnostic runs, scripts/gpu_upc_phases.py): shader-clock cycles of wave 0 spent in
+    // [0] phase-1 staging (barrier to barrier), [1] phase-1 MFMAs (+ the wait at the next barrier), [2] / [3] the same for phase 2,
+    // [4] epilogue: bias + output stores issued, [5] first LDS barrier + partial sums to LDS, [6] second barrier; [7] workgroups
+    long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+#define TS2D_STAMP(I) if (a.prof) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc[I] += t_ - tlast; tlast = t_; }
 
     // =================================================================================== phase 1: composed up half (coarse tensor)
     {
@@ -101,9 +106,23 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         // fragments: M-tile row r = coarse position (I = 2 mt + (r >> 4), J = r & 15); tap (dI, dJ) reads coarse patch pixel
         // (I + pA + dI, J + pB + dJ)
         const int abase = h * kUcPlane + (((r >> 4) + pA) * kUcPitch + (r & 15) + pB) * 16;      // + mt * 2 * pitch * 16 + (dI * pitch + dJ) * 16 + part * 2 * Plane
-        const int bbase = 4 * kUcPlane + (w * 4) * WT1 + h * BN * 16 + r * 16;                     // + tap * WT1 + part * 2 * BN * 16 + nt * 512
+        // B fragments: the 4 taps of THIS wave's parity - no other wave of the workgroup reads them, so they do not go through
+        // LDS (staging all 16 taps made this phase LDS-bound: 65 KB of weight writes per 48 MFMAs of a wave) but straight from
+        // L2 into a ring of 4 tap sets, each reloaded for the next chunk right after its MFMAs are issued (4 taps of lookahead).
+        // The weight image is already in fragment order: 16 bytes per lane, 512 contiguous bytes per lane half.
+        const unsigned char* wgl = reinterpret_cast<const unsigned char*>(a.wc) + ((size_t)ctile * 16 + w * 4) * WT1 + h * BN * 16 + r * 16;
+        const size_t wchunk = (size_t)a.n_ctiles * 16 * WT1;
+        half8 rb[4][NT][2];
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                rb[tap][nt][0] = *reinterpret_cast<const half8*>(wgl + tap * WT1 + nt * 512);
+                rb[tap][nt][1] = *reinterpret_cast<const half8*>(wgl + tap * WT1 + nt * 512 + 2 * BN * 16);
+            }
         for (int ch = 0; ch < nch; ++ch) {
             __syncthreads();
+            TS2D_STAMP(1)
             f32x4 nsa = f32x4{1.f, 1.f, 1.f, 1.f}, nsb = nsa, nta = f32x4{0.f, 0.f, 0.f, 0.f}, ntb = nta;
             const bool normed = a.scc != nullptr;
             if (normed) {
@@ -111,14 +130,6 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
                 nsa = *reinterpret_cast<const f32x4*>(ps); nsb = *reinterpret_cast<const f32x4*>(ps + 4);
                 nta = *reinterpret_cast<const f32x4*>(pt); ntb = *reinterpret_cast<const f32x4*>(pt + 4);
             }
-            // weights: 16 taps x 4 BN slots, linear copy (named registers)
-            constexpr int WU = 16 * BN * 4, WIT = WU / kBlock;       // 16 (BN = 64) or 8 (BN = 32) per thread
-            const uint4* wsrc = reinterpret_cast<const uint4*>(a.wc) + ((size_t)ch * a.n_ctiles + ctile) * WU;
-            uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;
-#define TS2D_WL(K, R) { if (K < WIT) R = wsrc[tid + K * kBlock]; }
-            TS2D_WL(0, w0) TS2D_WL(1, w1) TS2D_WL(2, w2) TS2D_WL(3, w3) TS2D_WL(4, w4) TS2D_WL(5, w5) TS2D_WL(6, w6) TS2D_WL(7, w7)
-            TS2D_WL(8, w8) TS2D_WL(9, w9) TS2D_WL(10, w10) TS2D_WL(11, w11) TS2D_WL(12, w12) TS2D_WL(13, w13) TS2D_WL(14, w14) TS2D_WL(15, w15)
-#undef TS2D_WL
             if (vo != 0x80000000u) {
                 f32x4 va = __builtin_bit_cast(f32x4, pv0), vb = __builtin_bit_cast(f32x4, pv1);
                 if (normed) {
@@ -131,12 +142,10 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
                 *reinterpret_cast<uint4*>(smem8 + lw) = hi;
                 *reinterpret_cast<uint4*>(smem8 + lw + 2 * kUcPlane) = lo;
             }
-#define TS2D_WS(K, R) { if (K < WIT) *reinterpret_cast<uint4*>(sB1 + (tid + K * kBlock) * 16) = R; }
-            TS2D_WS(0, w0) TS2D_WS(1, w1) TS2D_WS(2, w2) TS2D_WS(3, w3) TS2D_WS(4, w4) TS2D_WS(5, w5) TS2D_WS(6, w6) TS2D_WS(7, w7)
-            TS2D_WS(8, w8) TS2D_WS(9, w9) TS2D_WS(10, w10) TS2D_WS(11, w11) TS2D_WS(12, w12) TS2D_WS(13, w13) TS2D_WS(14, w14) TS2D_WS(15, w15)
-#undef TS2D_WS
             __syncthreads();
+            TS2D_STAMP(0)
             if (ch + 1 < nch) prefetch(ch + 1);
+            const unsigned char* wnext = wgl + (size_t)(ch + 1 < nch ? ch + 1 : ch) * wchunk;      // (last chunk: reloaded, never used - no branch)
             f32x16 acc_c[2][NT];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -148,29 +157,29 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
 #pragma unroll
             for (int tap = 0; tap < 4; ++tap) {
                 const int toff = ((tap >> 1) * kUcPitch + (tap & 1)) * 16;
-                half8 ah[2], al[2], bh[NT], bl[NT];
+                half8 ah[2], al[2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     ah[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff);
                     al[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff + 2 * kUcPlane);
                 }
 #pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], rb[tap][nt][0], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], rb[tap][nt][1], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], rb[tap][nt][0], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    bh[nt] = *reinterpret_cast<const half8*>(smem8 + bbase + tap * WT1 + nt * 512);
-                    bl[nt] = *reinterpret_cast<const half8*>(smem8 + bbase + tap * WT1 + nt * 512 + 2 * BN * 16);
+                    rb[tap][nt][0] = *reinterpret_cast<const half8*>(wnext + tap * WT1 + nt * 512);
+                    rb[tap][nt][1] = *reinterpret_cast<const half8*>(wnext + tap * WT1 + nt * 512 + 2 * BN * 16);
                 }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc_c[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc_c[mt][nt], 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -223,6 +232,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         for (int kx = 0; kx < 3; ++kx) tofs[kx] = ((((pB + kx) & 1) ? 20 : 0) + ((pB + kx) >> 1)) * 16;
         for (int ch = 0; ch < nch; ++ch) {
             __syncthreads();
+            TS2D_STAMP(3)
             f32x4 nsa = f32x4{1.f, 1.f, 1.f, 1.f}, nsb = nsa, nta = f32x4{0.f, 0.f, 0.f, 0.f}, ntb = nta;
             const bool normed = a.scs != nullptr;
             if (normed) {
@@ -255,6 +265,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
             TS2D_WS(0, w0) TS2D_WS(1, w1) TS2D_WS(2, w2) TS2D_WS(3, w3) TS2D_WS(4, w4) TS2D_WS(5, w5) TS2D_WS(6, w6) TS2D_WS(7, w7) TS2D_WS(8, w8)
 #undef TS2D_WS
             __syncthreads();
+            TS2D_STAMP(2)
             if (ch + 1 < nch) prefetch(ch + 1);
             f32x16 acc_c[2][NT];
 #pragma unroll
@@ -300,6 +311,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         }
     }
 
+    TS2D_STAMP(3)
     // =================================================================================== epilogue: scatter by parity, statistics
     // C/D map: column = lane & 31 (channel), row rho = (i & 3) + 8 (i >> 2) + 4 h -> (I = 2 mt + (rho >> 4), J = rho & 15)
     const float oscale = *a.oscale;
@@ -310,30 +322,49 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
-        const float bmid = a.bvar[4 * a.Cout + co];
+        // bias variants of this lane's channel, loaded ONCE (a load per element serialises the 64 stores of a wave behind 64 round
+        // trips to memory: measured 35 000 cycles per workgroup, in-kernel stamps of gpurun r2 upc_ph3)
+        float bvr[9];
+        bvr[4] = a.bvar[4 * a.Cout + co];
+        if (edge) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) if (k != 4) bvr[k] = a.bvar[k * a.Cout + co];
+        }
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             // lane part: J offset 4 h -> X offset 8 h pixels
             const unsigned voff = (unsigned)((((ty0 + 4 * mt + pA) * a.W + tx0 + 8 * h + pB) * a.Cout + co) * 4);
+            if (!edge) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int dI = i >> 3, dJ = (i & 3) + 8 * ((i >> 2) & 1);          // rho = (i&3) + 8 (i>>2): rho >> 4 = i >> 3, rho & 15 as here (+ 4 h)
-                const unsigned soff = (unsigned)(((2 * dI * a.W + 2 * dJ) * a.Cout) * 4);      // scalar
-                float bv = bmid;
-                if (edge) {
-                    const int Y = ty0 + 4 * mt + pA + 2 * dI, X = tx0 + pB + 2 * (dJ + 4 * h);
-                    const int ry = Y == 0 ? 0 : (Y == a.H - 1 ? 2 : 1), rx = X == 0 ? 0 : (X == a.W - 1 ? 2 : 1);
-                    bv = a.bvar[(ry * 3 + rx) * a.Cout + co];
+                for (int i = 0; i < 16; ++i) {
+                    const int dI = i >> 3, dJ = (i & 3) + 8 * ((i >> 2) & 1);          // rho = (i&3) + 8 (i>>2): rho >> 4 = i >> 3, rho & 15 as here (+ 4 h)
+                    const unsigned soff = (unsigned)(((2 * dI * a.W + 2 * dJ) * a.Cout) * 4);      // scalar
+                    const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bvr[4]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
+                    s += v; q = __builtin_fmaf(v, v, q);
                 }
-                const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
-                s += v; q = __builtin_fmaf(v, v, q);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int dI = i >> 3, dJ = (i & 3) + 8 * ((i >> 2) & 1);
+                    const unsigned soff = (unsigned)(((2 * dI * a.W + 2 * dJ) * a.Cout) * 4);
+                    const int Y = ty0 + 4 * mt + pA + 2 * dI, X = tx0 + pB + 2 * (dJ + 4 * h);      // Y wave-uniform, X per lane half
+                    const bool top = Y == 0, bot = Y == a.H - 1;
+                    const float b0 = top ? bvr[0] : (bot ? bvr[6] : bvr[3]);
+                    const float b1 = top ? bvr[1] : (bot ? bvr[7] : bvr[4]);
+                    const float b2 = top ? bvr[2] : (bot ? bvr[8] : bvr[5]);
+                    const float bv = X == 0 ? b0 : (X == a.W - 1 ? b2 : b1);
+                    const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
+                    s += v; q = __builtin_fmaf(v, v, q);
+                }
             }
         }
         st_s[nt] = s; st_q[nt] = q;
     }
-    __syncthreads();
+    TS2D_STAMP(4)
+    lds_barrier();
     float* red = reinterpret_cast<float*>(smem8);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -341,7 +372,9 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
         if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
     }
-    __syncthreads();
+    TS2D_STAMP(5)
+    lds_barrier();
+    TS2D_STAMP(6)
     if (tid < BN) {
         float s = 0.f, q = 0.f;
 #pragma unroll
@@ -349,6 +382,12 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
         p[0] = s; p[1] = q;
     }
+    if (a.prof && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) atomicAdd(a.prof + i, (unsigned long long)tacc[i]);
+        atomicAdd(a.prof + 7, 1ull);
+    }
+#undef TS2D_STAMP
 }
 
 }  // namespace ts2d

@@ -199,6 +199,11 @@ class Engine:
         _lib.check(self.lib.ts2d_engine_op_times(self._h, ms, n), 'ts2d_engine_op_times')
         return {self.lib.ts2d_engine_op_name(self._h, i).decode(): float(ms[i]) for i in range(n)}
 
+    def op_kernels(self) -> dict:
+        """op name -> name of the kernel that served it in the last profiled forward."""
+        n = self.lib.ts2d_engine_num_ops(self._h)
+        return {self.lib.ts2d_engine_op_name(self._h, i).decode(): self.lib.ts2d_engine_op_kernel(self._h, i).decode() for i in range(n)}
+
     def debug_tensor(self, name: str, capacity: int = 1 << 26) -> np.ndarray:
         """Test accessor: activation `name` of the last forward as torch would hold it (NCHW, norm+act applied)."""
         out = np.empty(capacity, dtype=np.float32)
