@@ -261,7 +261,7 @@ int build_program(ts2d_engine* e) {
             }
             const size_t oi = (size_t)(&op - e->ops.data());
             if (op.stride == 1 && op.skip >= 0 && oi > 0 && e->ops[oi - 1].type == OP_CONVT && e->ops[oi - 1].dst == op.src &&
-                e->ops[oi - 1].cin % 16 == 0 && op.cin % 16 == 0 && op.cin_skip % 16 == 0 && op.cout % 32 == 0 &&
+                e->ops[oi - 1].cin % 32 == 0 && op.cin % 16 == 0 && op.cin_skip % 16 == 0 && op.cout % 32 == 0 &&
                 (double)op.cout * e->ops[oi - 1].cin * op.cin * 36.0 <= 6.0e9) {        // (host composition cost bound: 512 x 512 x 512 channels = 4.8 GFLOP, about a second)
                 const int cb = e->ops[oi - 1].cin;
                 op.upc_ok = true; op.up_idx = (int)oi - 1;
@@ -926,9 +926,9 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             ua.tiles_x = Wt / 32; ua.tiles_y = Ht / 8; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y; ua.n_ctiles = op.cout / bn;
             ua.lg_nct = ilog2(ua.n_ctiles); ua.lg_tx = ilog2(ua.tiles_x); ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
             ua.slope = a.leaky_slope;
-            ua.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 8 * oi : nullptr;
+            ua.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
             const int grid = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
-            const size_t smem_u = std::max((size_t)4 * kUcPlane, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
+            const size_t smem_u = std::max((size_t)8 * kUcPlane, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
             TRY(prof_begin(e, op.name, st)); prof_kernel(e, bn == 64 ? "conv3x3_upc<64>" : "conv3x3_upc<32>");
             if (bn == 64) {
                 static std::atomic<uint64_t> done64{0};
@@ -957,6 +957,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const TileGeom g = tile_geom(B, Ht, Wt, stride, taps);
             ConvArgs ca{};
             ca.ksplit = 1; ca.dbg = e->dbg;
+            ca.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
             ca.src0 = src.data; ca.sc0 = src.scale; ca.sh0 = src.shift; ca.C0 = src.C;
             if (op.skip >= 0) { const Tensor& sk = e->tensors[op.skip]; ca.src1 = sk.data; ca.sc1 = sk.scale; ca.sh1 = sk.shift; ca.C1 = sk.C; }
             ca.wp = wts + op.dev_w; ca.bias = wts + op.dev_b; ca.dst = dst.data;
@@ -1228,8 +1229,8 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ws_event, hipEventDisableTiming);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&e->d_flags), 2 * sizeof(int));
     if (he == hipSuccess) he = hipMemset(e->d_flags, 0, 2 * sizeof(int));
-    if (he == hipSuccess && e->dbg == 256) he = hipMalloc(reinterpret_cast<void**>(&e->d_prof), 8 * 128 * sizeof(unsigned long long));
-    if (he == hipSuccess && e->d_prof) he = hipMemset(e->d_prof, 0, 8 * 128 * sizeof(unsigned long long));
+    if (he == hipSuccess && e->dbg == 256) he = hipMalloc(reinterpret_cast<void**>(&e->d_prof), 512 * 128 * sizeof(unsigned long long));
+    if (he == hipSuccess && e->d_prof) he = hipMemset(e->d_prof, 0, 512 * 128 * sizeof(unsigned long long));
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&e->d_weights), e->weight_floats * sizeof(float));
     if (he != hipSuccess) {
         rc = fail(he == hipErrorOutOfMemory ? TS2D_ERR_NOMEM : TS2D_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he));
@@ -1493,14 +1494,17 @@ const char* ts2d_engine_op_name(ts2d_engine* e, int op) {
 int ts2d_engine_op_times(ts2d_engine* e, float* ms, int n_ops) {
     if (!e || !ms) return fail(TS2D_ERR_INVALID, "ts2d_engine_op_times: null argument");
     if (e->d_prof) {        // TS2D_DBG=256: print and reset the in-kernel phase counters (cycles of wave 0, averaged over workgroups)
-        std::vector<unsigned long long> hp(8 * 128);
+        std::vector<unsigned long long> raw(512 * 128), hp(8 * 128, 0);
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(hp.data(), e->d_prof, hp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemset(e->d_prof, 0, hp.size() * sizeof(unsigned long long)));
+        HIP_TRY(hipMemcpy(raw.data(), e->d_prof, raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(e->d_prof, 0, raw.size() * sizeof(unsigned long long)));
+        for (size_t oi = 0; oi < 128; ++oi) for (int k = 0; k < 64; ++k) for (int i = 0; i < 8; ++i) hp[8 * oi + i] += raw[512 * oi + 8 * k + i];
         for (size_t oi = 0; oi < e->ops.size() && oi < 128; ++oi)
             if (hp[8 * oi + 7]) {
                 const double n = (double)hp[8 * oi + 7];
-                fprintf(stderr, "[phases] %-8s wgs %6.0f  cycles/wg: p1.stage %8.0f  p1.mfma %8.0f  p2.stage %8.0f  p2.mfma %8.0f  epi.stores %8.0f  epi.bar1 %8.0f  epi.bar2 %8.0f\n",
+                // conv3x3_upc: 0/1 phase-1 staging / MFMAs, 2/3 phase 2, 4 stores, 5 / 6 barriers.  p / s2v2: 0 staging (barrier to barrier), 1 MFMAs
+                // (+ wait at the next barrier), 3 last MFMAs, 4 bias + stores, 5 statistics.  q: 0 barrier wait, 1 chunk body, 3-5 as p.
+                fprintf(stderr, "[phases] %-8s wgs %6.0f  cycles/wg: [0] %8.0f  [1] %8.0f  [2] %8.0f  [3] %8.0f  [4] %8.0f  [5] %8.0f  [6] %8.0f\n",
                         e->ops[oi].name.c_str(), n, hp[8 * oi] / n, hp[8 * oi + 1] / n, hp[8 * oi + 2] / n, hp[8 * oi + 3] / n, hp[8 * oi + 4] / n, hp[8 * oi + 5] / n, hp[8 * oi + 6] / n);
             }
     }

@@ -17,6 +17,16 @@ namespace ts2d {
 // so that no memory operation moves across it.  (Never between an LDS-DMA and the reads of what it wrote.)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// In-kernel phase stamps (diagnostic runs, TS2D_DBG=256): wave 0 of every workgroup adds the shader-clock cycles between
+// consecutive stamps to slot I of its op's counters (64 sets of 8, picked by block index); slot 7 counts workgroups.  PROF is the pointer (nullptr in production:
+// one scalar compare per stamp).  This is how the serialised epilogue of conv3x3_upc was found (gpurun r2 upc_ph3).
+#define TS2D_PROF_DECL(PROF) long long tacc_[7] = {0, 0, 0, 0, 0, 0, 0}, tlast_ = (PROF) ? (long long)__builtin_readcyclecounter() : 0
+#define TS2D_STAMP_AT(PROF, I) if (PROF) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc_[I] += t_ - tlast_; tlast_ = t_; }
+#define TS2D_PROF_FLUSH(PROF) if ((PROF) && threadIdx.x == 0) {       /* 64 slot sets per op: no hot address */ \
+        unsigned long long* p_ = (PROF) + (blockIdx.x & 63) * 8; \
+        _Pragma("unroll") for (int i_ = 0; i_ < 7; ++i_) atomicAdd(p_ + i_, (unsigned long long)tacc_[i_]); \
+        atomicAdd(p_ + 7, 1ull); }
+
 
 constexpr int kBlock = 256;   // threads per workgroup (4 waves, one per SIMD)
 constexpr int kBM = 256;      // output pixels per workgroup tile
@@ -51,6 +61,7 @@ struct ConvArgs {
     const void* wph;      // split-fp16 packed weights [chunk][tap][N][16 hi | 16 lo] (f16x3 kernel only)
     int ksplit;           // split-K: blockIdx.y = K slice; slice s writes un-biased partials to dst + s * kslice_stride
     long long kslice_stride;
+    unsigned long long* prof;   // diagnostic (TS2D_DBG=256): in-kernel phase cycle counters of this op, 8 entries, or nullptr
     int dbg;              // timing ablations of diagnostic runs (TS2D_DBG; 0 in production): bit 0 = skip the MFMA phase, bit 1 = skip the
                           // patch conversion, bit 2 = skip the weight staging
     const float* oscale;  // device scalar: 1 / (power-of-two weight pre-scale); lives in the weight arena so that it

@@ -151,10 +151,13 @@ __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&a
     const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * sizeof(ST)), 0x00020000);
     float st_s[NT], st_q[NT];
+    float bvs[NT];       // every bias value before the first store: a load issued between stores waits (in-order vmcnt) for the stores ahead of it
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bvs[nt] = a.bias[n0col + nt * 32 + r];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
-        const float bv = a.bias[co];
+        const float bv = bvs[nt];
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {

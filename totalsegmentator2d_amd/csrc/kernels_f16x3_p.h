@@ -122,9 +122,11 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_f16x3_p(cons
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
 
+    TS2D_PROF_DECL(a.prof);
     for (int ch = 0; ch < nchunks; ++ch) {
         const bool normed = (ch * 16 < a.C0) ? (a.sc0 != nullptr) : (a.sc1 != nullptr);
         __syncthreads();   // the previous chunk's MFMA reads of LDS are done
+        TS2D_STAMP_AT(a.prof, 1)
         if (!PFS) load_st(ch);
         // ---- weights of this chunk: one linear block in LDS order; loads issued first (named registers)
         constexpr int WU = 9 * BN * 4, WIT = (WU + kBlock - 1) / kBlock;
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_f16x3_p(cons
         TS2D_WLOAD(0, w0) TS2D_WLOAD(1, w1) TS2D_WLOAD(2, w2) TS2D_WLOAD(3, w3) TS2D_WLOAD(4, w4)
         TS2D_WLOAD(5, w5) TS2D_WLOAD(6, w6) TS2D_WLOAD(7, w7) TS2D_WLOAD(8, w8)
 #undef TS2D_WLOAD
+        TS2D_STAMP_AT(a.prof, 2)
         // ---- patch: InstanceNorm + LeakyReLU on the fly, fp32 in -> fp16 hi / lo planes (padding slots stay zero)
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
@@ -153,12 +156,15 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_f16x3_p(cons
                 *reinterpret_cast<uint4*>(sA + lw[it] + 2 * kPPlane) = lo;
             }
         }
+        TS2D_STAMP_AT(a.prof, 4)
 #define TS2D_WSTORE(K, R) { const int idx = tid + K * kBlock; if (K < WIT && (WU % kBlock == 0 || idx < WU)) \
             *reinterpret_cast<uint4*>(sB + idx * 16) = R; }
         TS2D_WSTORE(0, w0) TS2D_WSTORE(1, w1) TS2D_WSTORE(2, w2) TS2D_WSTORE(3, w3) TS2D_WSTORE(4, w4)
         TS2D_WSTORE(5, w5) TS2D_WSTORE(6, w6) TS2D_WSTORE(7, w7) TS2D_WSTORE(8, w8)
 #undef TS2D_WSTORE
+        TS2D_STAMP_AT(a.prof, 6)
         __syncthreads();
+        TS2D_STAMP_AT(a.prof, 0)
         if (ch + 1 < nchunks) prefetch(ch + 1);       // HBM latency hides behind the MFMA phase
 
         // ---- 9 taps x (hi*lo + lo*hi + hi*hi) into a fresh accumulator (accuracy), added to acc_t;
@@ -228,7 +234,10 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_f16x3_p(cons
             for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
     }
 
+    TS2D_STAMP_AT(a.prof, 3)
     split_epilogue_one<BN, float>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin);
+    TS2D_STAMP_AT(a.prof, 5)
+    TS2D_PROF_FLUSH(a.prof)
 }
 
 }  // namespace ts2d

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_q(const ConvArgs a
     prefetch(nchunks > 1 ? 1 : 0);          // (past the end: the last chunk again - loaded, never used; keeps the loop branch-free)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+    TS2D_PROF_DECL(a.prof);
     const int abase = h * kQPlane + ((2 * w) * kPPW + r) * 16;
     const int bbase = h * BN * 16 + r * 16;
 
@@ -237,8 +238,11 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_q(const ConvArgs a
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
         // the DMA of chunk ch+1 has landed (only the patch prefetch of chunk ch+2 may stay in flight), this wave's LDS writes are done
+        TS2D_STAMP_AT(a.prof, 1)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        TS2D_STAMP_AT(a.prof, 0)
     }
+    TS2D_STAMP_AT(a.prof, 3)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: bias, store (C/D map of the 32x32 MFMA: column = lane & 31, rows (i & 3) + 8 (i >> 2) + 4 h), tile statistics
@@ -246,10 +250,13 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_q(const ConvArgs a
     const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * 4), 0x00020000);
     float st_s[NT], st_q[NT];
+    float bvs[NT];       // every bias value before the first store: a load issued between stores waits (in-order vmcnt) for the stores ahead of it
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bvs[nt] = a.bias[n0col + nt * 32 + r];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
-        const float bv = a.bias[co];
+        const float bv = bvs[nt];
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_q(const ConvArgs a
         }
         st_s[nt] = s; st_q[nt] = q;
     }
+    TS2D_STAMP_AT(a.prof, 4)
     float* red = reinterpret_cast<float*>(smem8);       // (all LDS reads ended at the loop's last barrier)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -281,6 +289,8 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_q(const ConvArgs a
         float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
         p[0] = s; p[1] = q;
     }
+    TS2D_STAMP_AT(a.prof, 5)
+    TS2D_PROF_FLUSH(a.prof)
 }
 
 }  // namespace ts2d

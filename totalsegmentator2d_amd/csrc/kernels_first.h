@@ -94,10 +94,13 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
     const size_t img_el = (size_t)a.H * a.W * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0,
                                                        (int)(full ? img_el * sizeof(ST) : 0), 0x00020000);
+    float bvs[NT];       // every bias value before the first store: a load issued between stores waits (in-order vmcnt) for the stores ahead of it
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bvs[nt] = a.bias[nt * 32 + r];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 32 + r;
-        const float bv = a.bias[co];
+        const float bv = bvs[nt];
         float ss = 0.f, qq = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {

@@ -103,8 +103,10 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
 
+    TS2D_PROF_DECL(a.prof);
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();                                   // the previous chunk's MFMA reads of LDS are done
+        TS2D_STAMP_AT(a.prof, 1)
         // scale / shift of this thread's 8 channels
         f32x4 nsa = f32x4{1.f, 1.f, 1.f, 1.f}, nsb = nsa, nta = f32x4{0.f, 0.f, 0.f, 0.f}, ntb = nta;
         const bool normed = a.sc0 != nullptr;
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         }
 #undef TS2D_WSTORE
         __syncthreads();
+        TS2D_STAMP_AT(a.prof, 0)
         if (ch + 1 < nchunks) prefetch(ch + 1);            // HBM latency hides behind the MFMA phase
 
         f32x16 acc_c[2][NTW];                              // fresh accumulator per chunk (accuracy)
@@ -206,10 +209,14 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * sizeof(ST)), 0x00020000);
     float st_s[NTW], st_q[NTW];
+    TS2D_STAMP_AT(a.prof, 3)
+    float bvs[NTW];       // every bias value before the first store: a load issued between stores waits (in-order vmcnt) for the stores ahead of it
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) bvs[nt] = a.bias[n0col + wn * (BN / 2) + nt * 32 + r];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int co = n0col + wn * (BN / 2) + nt * 32 + r;
-        const float bv = a.bias[co];
+        const float bv = bvs[nt];
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         }
         st_s[nt] = s; st_q[nt] = q;
     }
+    TS2D_STAMP_AT(a.prof, 4)
     lds_barrier();                                         // every wave is done with the LDS images (the output stores stay in flight)
     float* red = reinterpret_cast<float*>(smem8);          // [wm 4][column BN][2]
 #pragma unroll
@@ -242,6 +250,8 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
         p[0] = s; p[1] = q;
     }
+    TS2D_STAMP_AT(a.prof, 5)
+    TS2D_PROF_FLUSH(a.prof)
 }
 
 }  // namespace ts2d

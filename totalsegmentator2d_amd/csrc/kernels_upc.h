@@ -14,8 +14,8 @@
 //
 // Kernel: 256 threads, 8 x 32 output pixels x BN channels, 2-3 workgroups per CU (LDS: the phase-2 image, 62.5 KB at BN = 64).  The M dimension is grouped BY PARITY: wave w
 // owns parity class (A, B) = (w >> 1, w & 1), its two 32-row MFMA tiles are the 4 x 16 coarse positions (I, J) of the tile, i.e.
-// output pixels (2I + A, 2J + B).  Phase 1 walks the coarse channels in chunks of 16 (4 "taps" (dI, dJ) per wave: 4 x 12 MFMAs
-// for BN = 64), phase 2 the skip channels with the ordinary 9 taps (patch columns stored even-first / odd-second so that the
+// output pixels (2I + A, 2J + B).  Phase 1 walks the coarse channels in chunks of 32 (2 k-steps x 4 "taps" (dI, dJ) per wave: 96 MFMAs
+// for BN = 64 between two barriers), phase 2 the skip channels with the ordinary 9 taps (patch columns stored even-first / odd-second so that the
 // stride-2 pixel walk of a fragment is a walk over consecutive LDS slots).  k-group-major planes as in kernels_f16x3_p.h; row
 // pitches (32 / 40 slots) chosen so that the two 16-lane runs of a fragment read fall on disjoint slot residues.
 #pragma once
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
     const int r = lane & 31, h = lane >> 5;
     const int octi = (lane >> 3) & 1, oct = octi * 8;
 
-    // LDS: phase 1 [coarse planes 4 x kUcPlane]; phase 2 [skip planes 4 x kUsPlane | weights] (same memory)
+    // LDS: phase 1 [coarse planes 8 x kUcPlane: 32-channel chunks]; phase 2 [skip planes 4 x kUsPlane | weights] (same memory)
     unsigned char* sB2 = smem8 + 4 * kUsPlane;
 
     f32x16 acc_t[2][NT];
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
     // in-kernel phase stamps (a.prof != nullptr: diagnostic runs, scripts/gpu_upc_phases.py): shader-clock cycles of wave 0 spent in
     // [0] phase-1 staging (barrier to barrier), [1] phase-1 MFMAs (+ the wait at the next barrier), [2] / [3] the same for phase 2,
     // [4] epilogue: bias + output stores issued, [5] first LDS barrier + partial sums to LDS, [6] second barrier; [7] workgroups
-    long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = a.prof ? (long long)__builtin_readcyclecounter() : 0;
-#define TS2D_STAMP(I) if (a.prof) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc[I] += t_ - tlast; tlast = t_; }
+    TS2D_PROF_DECL(a.prof);
+#define TS2D_STAMP(I) TS2D_STAMP_AT(a.prof, I)
 
     // =================================================================================== phase 1: composed up half (coarse tensor)
     {
@@ -87,31 +87,38 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         const int pp = 32 * w + (lane & 7) + 8 * (lane >> 4);
         const int py = pp / 18, px = pp - py * 18;
         const int iy = (ty0 >> 1) - 1 + py, ix = (tx0 >> 1) - 1 + px;
+        // LDS planes of a 32-channel chunk: [k-step 2][part hi,lo][h][slot]: plane (ks, part, h) at ((ks * 2 + part) * 2 + h) * kUcPlane
         const int lw = octi * kUcPlane + (py * kUcPitch + px) * 16;
         unsigned vo = 0x80000000u;
         if (pp < 108) {
             if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) vo = (unsigned)(((iy * Wc + ix) * a.Cb + oct) * 4);
-            else { *reinterpret_cast<uint4*>(smem8 + lw) = uint4{0u, 0u, 0u, 0u};
-                   *reinterpret_cast<uint4*>(smem8 + lw + 2 * kUcPlane) = uint4{0u, 0u, 0u, 0u}; }
+            else {
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) *reinterpret_cast<uint4*>(smem8 + lw + 2 * pl * kUcPlane) = uint4{0u, 0u, 0u, 0u};
+            }
         }
         const size_t img_px = (size_t)Hc * Wc;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xc) + (size_t)nimg0 * img_px * a.Cb, 0, (int)(img_px * a.Cb * 4), 0x00020000);
-        const int nch = a.Cb / 16;
-        u32x4 pv0, pv1;
+        const int nch = a.Cb / 32;                          // chunks of 32 coarse channels = 2 k-steps (the engine checks Cb % 32 == 0)
+        u32x4 pv[2][2];
         auto prefetch = [&](int ch) {
-            pv0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, ch * 64, 0);
-            pv1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16, ch * 64, 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                pv[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + ks * 64, ch * 128, 0);
+                pv[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + ks * 64 + 16, ch * 128, 0);
+            }
         };
         prefetch(0);
         // fragments: M-tile row r = coarse position (I = 2 mt + (r >> 4), J = r & 15); tap (dI, dJ) reads coarse patch pixel
         // (I + pA + dI, J + pB + dJ)
-        const int abase = h * kUcPlane + (((r >> 4) + pA) * kUcPitch + (r & 15) + pB) * 16;      // + mt * 2 * pitch * 16 + (dI * pitch + dJ) * 16 + part * 2 * Plane
+        const int abase = h * kUcPlane + (((r >> 4) + pA) * kUcPitch + (r & 15) + pB) * 16;      // + ks * 4 planes + part * 2 planes + mt * 2 * pitch * 16 + (dI * pitch + dJ) * 16
         // B fragments: the 4 taps of THIS wave's parity - no other wave of the workgroup reads them, so they do not go through
         // LDS (staging all 16 taps made this phase LDS-bound: 65 KB of weight writes per 48 MFMAs of a wave) but straight from
-        // L2 into a ring of 4 tap sets, each reloaded for the next chunk right after its MFMAs are issued (4 taps of lookahead).
+        // L2 into a ring of 4 tap sets, each reloaded for the next k-step right after its MFMAs are issued (4 taps of lookahead).
         // The weight image is already in fragment order: 16 bytes per lane, 512 contiguous bytes per lane half.
         const unsigned char* wgl = reinterpret_cast<const unsigned char*>(a.wc) + ((size_t)ctile * 16 + w * 4) * WT1 + h * BN * 16 + r * 16;
-        const size_t wchunk = (size_t)a.n_ctiles * 16 * WT1;
+        const size_t wchunk = (size_t)a.n_ctiles * 16 * WT1;       // bytes per 16-channel k-step
+        const int nks = 2 * nch;
         half8 rb[4][NT][2];
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap)
@@ -120,32 +127,31 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
                 rb[tap][nt][0] = *reinterpret_cast<const half8*>(wgl + tap * WT1 + nt * 512);
                 rb[tap][nt][1] = *reinterpret_cast<const half8*>(wgl + tap * WT1 + nt * 512 + 2 * BN * 16);
             }
+        const bool normed = a.scc != nullptr;
         for (int ch = 0; ch < nch; ++ch) {
             __syncthreads();
             TS2D_STAMP(1)
-            f32x4 nsa = f32x4{1.f, 1.f, 1.f, 1.f}, nsb = nsa, nta = f32x4{0.f, 0.f, 0.f, 0.f}, ntb = nta;
-            const bool normed = a.scc != nullptr;
-            if (normed) {
-                const float* ps = a.scc + (size_t)nimg0 * a.Cb + ch * 16 + oct; const float* pt = a.shc + (size_t)nimg0 * a.Cb + ch * 16 + oct;
-                nsa = *reinterpret_cast<const f32x4*>(ps); nsb = *reinterpret_cast<const f32x4*>(ps + 4);
-                nta = *reinterpret_cast<const f32x4*>(pt); ntb = *reinterpret_cast<const f32x4*>(pt + 4);
-            }
             if (vo != 0x80000000u) {
-                f32x4 va = __builtin_bit_cast(f32x4, pv0), vb = __builtin_bit_cast(f32x4, pv1);
-                if (normed) {
-                    va = va * nsa + nta; vb = vb * nsb + ntb;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { va[e] = fmaxf(va[e], va[e] * a.slope); vb[e] = fmaxf(vb[e], vb[e] * a.slope); }
+                for (int ks = 0; ks < 2; ++ks) {
+                    f32x4 va = __builtin_bit_cast(f32x4, pv[ks][0]), vb = __builtin_bit_cast(f32x4, pv[ks][1]);
+                    if (normed) {
+                        const float* ps = a.scc + (size_t)nimg0 * a.Cb + ch * 32 + ks * 16 + oct; const float* pt = a.shc + (size_t)nimg0 * a.Cb + ch * 32 + ks * 16 + oct;
+                        const f32x4 nsa = *reinterpret_cast<const f32x4*>(ps), nsb = *reinterpret_cast<const f32x4*>(ps + 4);
+                        const f32x4 nta = *reinterpret_cast<const f32x4*>(pt), ntb = *reinterpret_cast<const f32x4*>(pt + 4);
+                        va = va * nsa + nta; vb = vb * nsb + ntb;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { va[e] = fmaxf(va[e], va[e] * a.slope); vb[e] = fmaxf(vb[e], vb[e] * a.slope); }
+                    }
+                    uint4 hi, lo;
+                    split_hi_lo_8(va, vb, hi, lo);
+                    *reinterpret_cast<uint4*>(smem8 + lw + ks * 4 * kUcPlane) = hi;
+                    *reinterpret_cast<uint4*>(smem8 + lw + ks * 4 * kUcPlane + 2 * kUcPlane) = lo;
                 }
-                uint4 hi, lo;
-                split_hi_lo_8(va, vb, hi, lo);
-                *reinterpret_cast<uint4*>(smem8 + lw) = hi;
-                *reinterpret_cast<uint4*>(smem8 + lw + 2 * kUcPlane) = lo;
             }
             __syncthreads();
             TS2D_STAMP(0)
             if (ch + 1 < nch) prefetch(ch + 1);
-            const unsigned char* wnext = wgl + (size_t)(ch + 1 < nch ? ch + 1 : ch) * wchunk;      // (last chunk: reloaded, never used - no branch)
             f32x16 acc_c[2][NT];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -155,30 +161,35 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
                     for (int i = 0; i < 16; ++i) acc_c[mt][nt][i] = 0.f;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int tap = 0; tap < 4; ++tap) {
-                const int toff = ((tap >> 1) * kUcPitch + (tap & 1)) * 16;
-                half8 ah[2], al[2];
+            for (int ks = 0; ks < 2; ++ks) {
+                const int knext = 2 * ch + ks + 1 < nks ? 2 * ch + ks + 1 : 2 * ch + ks;      // (last k-step: reloaded, never used - no branch)
+                const unsigned char* wnext = wgl + (size_t)knext * wchunk;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    ah[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff);
-                    al[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff + 2 * kUcPlane);
-                }
+                for (int tap = 0; tap < 4; ++tap) {
+                    const int toff = ks * 4 * kUcPlane + ((tap >> 1) * kUcPitch + (tap & 1)) * 16;
+                    half8 ah[2], al[2];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                    for (int mt = 0; mt < 2; ++mt) {
+                        ah[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff);
+                        al[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff + 2 * kUcPlane);
+                    }
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], rb[tap][nt][0], acc_c[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                        for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], rb[tap][nt][0], acc_c[mt][nt], 0, 0, 0);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], rb[tap][nt][1], acc_c[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                        for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], rb[tap][nt][1], acc_c[mt][nt], 0, 0, 0);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], rb[tap][nt][0], acc_c[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    rb[tap][nt][0] = *reinterpret_cast<const half8*>(wnext + tap * WT1 + nt * 512);
-                    rb[tap][nt][1] = *reinterpret_cast<const half8*>(wnext + tap * WT1 + nt * 512 + 2 * BN * 16);
+                        for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], rb[tap][nt][0], acc_c[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        rb[tap][nt][0] = *reinterpret_cast<const half8*>(wnext + tap * WT1 + nt * 512);
+                        rb[tap][nt][1] = *reinterpret_cast<const half8*>(wnext + tap * WT1 + nt * 512 + 2 * BN * 16);
+                    }
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -319,17 +330,24 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(a.dst + (size_t)nimg0 * img_el, 0, (int)(img_el * 4), 0x00020000);
     const bool edge = tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1;       // wave-uniform
     float st_s[NT], st_q[NT];
+    // bias variants of this lane's channels, all loaded before the first store (a load per element serialised the 64 stores of a
+    // wave behind 64 round trips to memory: measured 35 000 cycles per workgroup, in-kernel stamps of gpurun r2 upc_ph3; a load
+    // between stores still waits - in-order vmcnt - for the stores ahead of it)
+    // (nine separate arrays, not one [9]: a select among elements of one array becomes an indexed load from scratch)
+    float bv0[NT], bv1[NT], bv2[NT], bv3[NT], bv4[NT], bv5[NT], bv6[NT], bv7[NT], bv8[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float* pb = a.bvar + n0col + nt * 32 + r;
+        bv4[nt] = pb[4 * a.Cout];
+        bv0[nt] = bv1[nt] = bv2[nt] = bv3[nt] = bv5[nt] = bv6[nt] = bv7[nt] = bv8[nt] = 0.f;
+        if (edge) {
+            bv0[nt] = pb[0]; bv1[nt] = pb[a.Cout]; bv2[nt] = pb[2 * a.Cout]; bv3[nt] = pb[3 * a.Cout];
+            bv5[nt] = pb[5 * a.Cout]; bv6[nt] = pb[6 * a.Cout]; bv7[nt] = pb[7 * a.Cout]; bv8[nt] = pb[8 * a.Cout];
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
-        // bias variants of this lane's channel, loaded ONCE (a load per element serialises the 64 stores of a wave behind 64 round
-        // trips to memory: measured 35 000 cycles per workgroup, in-kernel stamps of gpurun r2 upc_ph3)
-        float bvr[9];
-        bvr[4] = a.bvar[4 * a.Cout + co];
-        if (edge) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) if (k != 4) bvr[k] = a.bvar[k * a.Cout + co];
-        }
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -340,7 +358,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
                 for (int i = 0; i < 16; ++i) {
                     const int dI = i >> 3, dJ = (i & 3) + 8 * ((i >> 2) & 1);          // rho = (i&3) + 8 (i>>2): rho >> 4 = i >> 3, rho & 15 as here (+ 4 h)
                     const unsigned soff = (unsigned)(((2 * dI * a.W + 2 * dJ) * a.Cout) * 4);      // scalar
-                    const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bvr[4]);
+                    const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv4[nt]);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
                     s += v; q = __builtin_fmaf(v, v, q);
                 }
@@ -351,9 +369,9 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
                     const unsigned soff = (unsigned)(((2 * dI * a.W + 2 * dJ) * a.Cout) * 4);
                     const int Y = ty0 + 4 * mt + pA + 2 * dI, X = tx0 + pB + 2 * (dJ + 4 * h);      // Y wave-uniform, X per lane half
                     const bool top = Y == 0, bot = Y == a.H - 1;
-                    const float b0 = top ? bvr[0] : (bot ? bvr[6] : bvr[3]);
-                    const float b1 = top ? bvr[1] : (bot ? bvr[7] : bvr[4]);
-                    const float b2 = top ? bvr[2] : (bot ? bvr[8] : bvr[5]);
+                    const float b0 = top ? bv0[nt] : (bot ? bv6[nt] : bv3[nt]);
+                    const float b1 = top ? bv1[nt] : (bot ? bv7[nt] : bv4[nt]);
+                    const float b2 = top ? bv2[nt] : (bot ? bv8[nt] : bv5[nt]);
                     const float bv = X == 0 ? b0 : (X == a.W - 1 ? b2 : b1);
                     const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
@@ -382,11 +400,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
         p[0] = s; p[1] = q;
     }
-    if (a.prof && tid == 0) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) atomicAdd(a.prof + i, (unsigned long long)tacc[i]);
-        atomicAdd(a.prof + 7, 1ull);
-    }
+    TS2D_PROF_FLUSH(a.prof)
 #undef TS2D_STAMP
 }
 
