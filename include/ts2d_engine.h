@@ -147,6 +147,17 @@ int ts2d_engine_tiled_inf_flag(const ts2d_engine* e);
 int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
                          long long sy, long long sx, long long base, float* out_max, float* out_mean);
 
+/* The same projection followed, on the device, by the per-channel z-score nnU-Net applies to the 2-channel (max, mean) image
+ * before the network (ZScoreNormalization without mask: (x - mean) / max(std, 1e-8), population std; reference flow
+ * ts2d/tool.py:152-160,182-185 -> DefaultPreprocessor.run_case, ts2d/core/inference/prediction_worker.py:194-199): mean and std in
+ * float64, two passes, fixed summation order.  out_norm = [2][nz][nx] float (the network input when nz, nx need no padding),
+ * out_stats = {mean_max, std_max, mean_mean, std_mean} (may be NULL), out_box = {first, last non-zero row, first, last non-zero
+ * column} over both channels (may be NULL): nnU-Net crops to that box BEFORE normalising, so the caller uses out_norm only when
+ * the box is the whole image.  (ABI 4) */
+int ts2d_project_coronal_zscore(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
+                                long long sy, long long sx, long long base, float* out_max, float* out_mean, float* out_norm,
+                                double* out_stats, int32_t* out_box);
+
 /* Synthetic slice stream on the device (BASELINE config 4: "synthetic 10k-slice stream", generated per rank from (seed, slice
  * index) so that no host transfer skews the timing).  Writes n_elements fp32 values, approximately N(0,1), to device memory:
  * element i of the call = element (first_element + i) of the stream identified by `key`; a value depends on (key, element index)

@@ -77,3 +77,27 @@ def test_overflowing_transposed_conv_output_is_an_error_naming_the_layer(monkeyp
         e.load_weights(blob_ok)                            # the flag does not stick: sane weights, same engine
         good, _ = e.forward(x)
         assert np.isfinite(good).all()
+
+
+def test_two_engines_on_two_devices_of_one_process():
+    """Handles are independent (include/ts2d_engine.h): two engines on two devices of ONE process, interleaved calls, identical
+    results.  Exercises the per-device state of `allow_max_lds` (hipFuncAttributeMaxDynamicSharedMemorySize is a per-device
+    property of a kernel; ADVICE r1: the "already set" flags used to be per process).  Needs two visible GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two visible GPUs (the GPU box of this round has one)')
+    from totalsegmentator2d_amd.arch import UNetArch
+    arch = UNetArch.canonical(num_classes=5)
+    sd = weights.synthetic_state_dict(arch, 77)
+    blob = weights.pack_blob(arch, sd)
+    x = cases.make_input(arch, 2, 256, 256, 77)
+    with Engine(arch, blob, device=1) as e1:                   # device 1 FIRST: its kernels need the attribute before device 0 ever ran
+        l1, m1 = e1.forward(x, logits=True, mask=True)
+        with Engine(arch, blob, device=0) as e0:
+            l0, m0 = e0.forward(x, logits=True, mask=True)
+            l1b, _ = e1.forward(x, logits=True)
+            for mode in ('exact', 'f16'):
+                e0.set_precision(mode); e1.set_precision(mode)
+                a, _ = e0.forward(x, logits=True); b, _ = e1.forward(x, logits=True)
+                assert np.array_equal(a, b), mode
+    assert np.array_equal(l0, l1) and np.array_equal(l1, l1b) and np.array_equal(m0, m1)

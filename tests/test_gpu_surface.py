@@ -56,3 +56,47 @@ def test_gpu_projection_equals_host_projection():
                 assert np.allclose(got[mode].array, ref.array, rtol=1e-6, atol=1e-4)
             else:
                 assert np.array_equal(got[mode].array, ref.array), mode
+
+
+def test_device_zscore_behind_the_projection():
+    """ts2d_project_coronal_zscore: the per-channel z-score of the (max, mean) projections on the device (float64 two-pass
+    statistics) against numpy - float32 values to a few ulps, statistics to float64 accuracy - and its use by the preprocessor:
+    taken when nnU-Net's crop-to-nonzero is the identity, ignored (host pass, bit-identical to before) when it is not."""
+    from types import SimpleNamespace
+    from totalsegmentator2d_amd import image, preprocess
+    rng = np.random.default_rng(5)
+    eye = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
+    full = nrrd.Image((rng.normal(0, 300, (40, 33, 50)) - 200).astype(np.int16), (1.5, 1.5, 1.5), (0.0, 0.0, 0.0), eye, 1, {}, None)
+    framed = np.zeros((30, 20, 40), np.int16)
+    framed[5:25, :, 8:30] = rng.integers(-900, 900, (20, 20, 22))
+    framed = nrrd.Image(framed, (1.5, 1.5, 1.5), (0.0, 0.0, 0.0), eye, 1, {}, None)
+    v = nrrd.read(os.path.join(A, 'sample_s0521.nrrd'))
+    for vol, expect_full in ((full, True), (v, None), (framed, False)):
+        got = image.project_coronal_gpu(vol, zscore=True)
+        zs = got['zscore']
+        nz, nx = zs['shape']
+        planes = [got[m].array.reshape(nz, nx) for m in ('max', 'mean')]
+        for k, x in enumerate(planes):
+            ref = preprocess.zscore(x)
+            assert np.abs(zs['norm'][k] - ref).max() <= 4e-6 * max(1.0, float(np.abs(ref).max())), k
+            x64 = x.astype(np.float64)
+            assert abs(zs['stats'][2 * k] - x64.mean()) <= 1e-9 * max(1.0, abs(x64.mean()))
+            assert abs(zs['stats'][2 * k + 1] - x64.std()) <= 1e-9 * max(1.0, x64.std())
+        nzmask = (planes[0] != 0) | (planes[1] != 0)
+        rows, cols = np.where(nzmask.any(1))[0], np.where(nzmask.any(0))[0]
+        assert zs['box'] == (rows[0], rows[-1], cols[0], cols[-1])
+        is_full = zs['box'] == (0, nz - 1, 0, nx - 1)
+        if expect_full is not None:
+            assert is_full == expect_full
+        # the preprocessor: same call with and without the device result
+        data = np.stack(planes)[:, None].astype(np.float32)
+        pm, cm = SimpleNamespace(transpose_forward=[0, 1, 2]), SimpleNamespace(spacing=(1.5, 1.5))
+        pre = preprocess.DefaultPreprocessor(verbose=False)
+        host, _, ph = pre.run_case_npy(data.copy(), None, {'spacing': (999.0, 1.5, 1.5)}, pm, cm, {})
+        dev, _, pd = pre.run_case_npy(data.copy(), None, {'spacing': (999.0, 1.5, 1.5), 'device_zscore': dict(zs, order=(0, 1))}, pm, cm, {})
+        assert ph['bbox_used_for_cropping'] == pd['bbox_used_for_cropping'] and host.shape == dev.shape
+        if is_full:
+            assert np.array_equal(dev[:, 0], zs['norm'])
+            assert np.abs(dev - host).max() <= 4e-6 * max(1.0, float(np.abs(host).max()))
+        else:
+            assert np.array_equal(dev, host)                      # cropped first on the host: the device planes do not apply

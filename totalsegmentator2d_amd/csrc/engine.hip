@@ -1196,7 +1196,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
 // ------------------------------------------------------------------------------------------------- C-ABI
 extern "C" {
 
-int ts2d_abi_version(void) { return 3; }
+int ts2d_abi_version(void) { return 4; }
 
 const char* ts2d_last_error(void) { return g_err.c_str(); }
 
@@ -1421,8 +1421,8 @@ int ts2d_engine_check(ts2d_engine* e) {
 
 int ts2d_engine_tiled_inf_flag(const ts2d_engine* e) { return e ? (e->tiled_inf != 0) : 0; }
 
-int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
-                         long long sy, long long sx, long long base, float* out_max, float* out_mean) {
+static int project_coronal_impl(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
+                                long long sy, long long sx, long long base, float* out_max, float* out_mean, float* out_norm, double* out_stats, int* out_box) {
     if (!volume || !out_max || !out_mean) return fail(TS2D_ERR_INVALID, "ts2d_project_coronal: null argument");
     static const int esize[5] = {2, 1, 4, 2, 4};
     if (dtype < 0 || dtype > 4 || nz < 1 || ny < 1 || nx < 1) return fail(TS2D_ERR_INVALID, "ts2d_project_coronal: bad dtype / extents");
@@ -1435,9 +1435,12 @@ int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dty
     HIP_TRY(hipSetDevice(device));
     const size_t vbytes = n_elems * esize[dtype], obytes = (size_t)nz * nx * sizeof(float);
     char* d = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), align_up(vbytes, 256) + 2 * align_up(obytes, 256)));
-    float* d_max = reinterpret_cast<float*>(d + align_up(vbytes, 256));
-    float* d_mean = reinterpret_cast<float*>(d + align_up(vbytes, 256) + align_up(obytes, 256));
+    // [volume | max | mean (contiguous: the two channels of the z-score) | normalised x 2 | partial sums | stats | box]
+    const size_t o_proj = align_up(vbytes, 256), o_norm = align_up(o_proj + 2 * obytes, 256), o_part = align_up(o_norm + 2 * obytes, 256);
+    const size_t o_stats = o_part + 2 * kZBlocks * sizeof(double), o_box = o_stats + 4 * sizeof(double);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), o_box + 4 * sizeof(int)));
+    float* d_max = reinterpret_cast<float*>(d + o_proj);
+    float* d_mean = d_max + (size_t)nz * nx;
     hipError_t he = hipMemcpy(d, volume, vbytes, hipMemcpyHostToDevice);
     if (he == hipSuccess) {
         const unsigned grid = (unsigned)(((long long)nz * nx + 255) / 256);
@@ -1450,6 +1453,25 @@ int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dty
         }
         he = hipGetLastError();
     }
+    if (he == hipSuccess && out_norm) {          // per-channel z-score of (max, mean): float64 two-pass statistics, deterministic
+        const long long n = (long long)nz * nx;
+        float* d_norm = reinterpret_cast<float*>(d + o_norm);
+        double* d_part = reinterpret_cast<double*>(d + o_part); double* d_stats = reinterpret_cast<double*>(d + o_stats);
+        int* d_box = reinterpret_cast<int*>(d + o_box);
+        const int box0[4] = {nz, -1, nx, -1};
+        he = hipMemcpy(d_box, box0, sizeof(box0), hipMemcpyHostToDevice);
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(zs_partial<0>, dim3(kZBlocks, 2), dim3(256), 0, 0, d_max, n, d_stats, d_part);
+            hipLaunchKernelGGL(zs_combine<0>, dim3(1), dim3(2), 0, 0, d_part, n, d_stats);
+            hipLaunchKernelGGL(zs_partial<1>, dim3(kZBlocks, 2), dim3(256), 0, 0, d_max, n, d_stats, d_part);
+            hipLaunchKernelGGL(zs_combine<1>, dim3(1), dim3(2), 0, 0, d_part, n, d_stats);
+            hipLaunchKernelGGL(zs_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_max, n, nx, 2, d_stats, d_norm, d_box);
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipMemcpy(out_norm, d_norm, 2 * obytes, hipMemcpyDeviceToHost);
+        if (he == hipSuccess && out_stats) he = hipMemcpy(out_stats, d_stats, 4 * sizeof(double), hipMemcpyDeviceToHost);
+        if (he == hipSuccess && out_box) he = hipMemcpy(out_box, d_box, 4 * sizeof(int), hipMemcpyDeviceToHost);
+    }
     if (he == hipSuccess) he = hipMemcpy(out_max, d_max, obytes, hipMemcpyDeviceToHost);
     if (he == hipSuccess) he = hipMemcpy(out_mean, d_mean, obytes, hipMemcpyDeviceToHost);
     (void)hipFree(d);
@@ -1457,6 +1479,18 @@ int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dty
     return TS2D_OK;
 }
 
+
+int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
+                         long long sy, long long sx, long long base, float* out_max, float* out_mean) {
+    return project_coronal_impl(device, volume, n_elems, dtype, nz, ny, nx, sz, sy, sx, base, out_max, out_mean, nullptr, nullptr, nullptr);
+}
+
+int ts2d_project_coronal_zscore(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
+                                long long sy, long long sx, long long base, float* out_max, float* out_mean, float* out_norm,
+                                double* out_stats, int32_t* out_box) {
+    if (!out_norm) return fail(TS2D_ERR_INVALID, "ts2d_project_coronal_zscore: null argument");
+    return project_coronal_impl(device, volume, n_elems, dtype, nz, ny, nx, sz, sy, sx, base, out_max, out_mean, out_norm, out_stats, out_box);
+}
 int ts2d_synth_slices(int device, unsigned long long key, unsigned long long first_element, unsigned long long n_elements,
                       float* out_device, void* stream) {
     if (!out_device) return fail(TS2D_ERR_INVALID, "ts2d_synth_slices: null output");

@@ -28,6 +28,55 @@ __global__ void project_coronal(const T* __restrict__ vol, int nz, int ny, int n
     }
 }
 
+// Per-channel z-score of the two projections (nnU-Net ZScoreNormalization without mask, the step between TS2D._project and the
+// network: ts2d/tool.py:152-160,182-185 -> prediction_worker.py:194-199): mean and population standard deviation in float64,
+// two passes, (x - mean) / max(std, 1e-8) rounded once to float.  Deterministic: kZBlocks fixed-size partial sums per channel,
+// added in index order by ONE thread (no float atomics).  zs_partial<0>: sum(x); zs_partial<1>: sum((x - mean)^2).
+constexpr int kZBlocks = 64;
+
+template <int PASS>
+__global__ __launch_bounds__(256) void zs_partial(const float* __restrict__ x, long long n, const double* __restrict__ stats, double* __restrict__ part) {
+    // grid = (kZBlocks, channels); x = [channels][n]; stats = [channels][2] (mean, std); part = [channels][kZBlocks]
+    const int c = blockIdx.y;
+    const float* p = x + (long long)c * n;
+    const double mean = PASS ? stats[2 * c] : 0.0;
+    const long long per = (n + kZBlocks - 1) / kZBlocks, lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+    double acc = 0.0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) { const double d = (double)p[i] - mean; acc += PASS ? d * d : d; }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) part[c * kZBlocks + blockIdx.x] = red[0];
+}
+
+template <int PASS>
+__global__ void zs_combine(const double* __restrict__ part, long long n, double* __restrict__ stats) {
+    const int c = threadIdx.x;                     // one thread per channel
+    double s = 0.0;
+    for (int b = 0; b < kZBlocks; ++b) s += part[c * kZBlocks + b];
+    if (PASS == 0) stats[2 * c] = s / (double)n; else stats[2 * c + 1] = sqrt(s / (double)n);
+}
+
+// normalise + the non-zero bounding box of the UN-normalised data over all channels (nnU-Net crops to it before normalising: the
+// caller uses the device result only when the box is the whole image).  box = {min row, max row, min col, max col} via integer atomics.
+__global__ void zs_apply(const float* __restrict__ x, long long n, int nx, int channels, const double* __restrict__ stats,
+                         float* __restrict__ out, int* __restrict__ box) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool nz = false;
+    for (int c = 0; c < channels; ++c) {
+        const float v = x[(long long)c * n + i];
+        nz |= v != 0.f;
+        const double sd = stats[2 * c + 1] > 1e-8 ? stats[2 * c + 1] : 1e-8;
+        out[(long long)c * n + i] = (float)(((double)v - stats[2 * c]) / sd);
+    }
+    if (nz) {
+        const int row = (int)(i / nx), col = (int)(i % nx);
+        atomicMin(box + 0, row); atomicMax(box + 1, row); atomicMin(box + 2, col); atomicMax(box + 3, col);
+    }
+}
+
 // Synthetic slice stream (BASELINE config 4: "synthetic 10k-slice stream ... generated on device per rank from (seed, slice_index)"):
 // the portable counter-based generator of totalsegmentator2d_amd/prng.py restated for the device - splitmix64 of the element
 // counter, eight 16-bit uniforms summed (Irwin-Hall) and standardised in double, rounded once to float.  Element e of the stream

@@ -99,10 +99,15 @@ def _reorient_plan(img: Image):
     return perm, flips
 
 
-def project_coronal_gpu(img: Image, device: int = 0):
+def project_coronal_gpu(img: Image, device: int = 0, zscore: bool = False):
     """max and mean coronal projections of a 3-D volume on the MI355X (C-ABI ``ts2d_project_coronal``): equals
     ``project(reorient_image(img), mode, 'coronal')`` for mode in (max, mean), as float32 images, without the host-side
-    reorientation copy.  Returns {'max': Image, 'mean': Image} with size (nx, 1, nz)."""
+    reorientation copy.  Returns {'max': Image, 'mean': Image} with size (nx, 1, nz).
+
+    ``zscore=True`` (C-ABI ``ts2d_project_coronal_zscore``) also normalises both projections on the device - nnU-Net's
+    ZScoreNormalization, float64 statistics - and returns them under ``'zscore'``: ``{'norm': [2, nz, nx] float32 in
+    (max, mean) order, 'stats': (mean, std) x 2, 'box': non-zero bounding box}``; ``DefaultPreprocessor.run_case_npy`` uses it
+    in place of its host pass when nnU-Net's crop-to-nonzero is the identity (``preprocess.py``)."""
     import ctypes
     from . import _lib
     if img.dimension != 3 or img.components != 1 or img.array.dtype.name not in _GPU_DTYPES:
@@ -119,11 +124,22 @@ def project_coronal_gpu(img: Image, device: int = 0):
     sz, sy, sx = (s // it for s in view.strides)
     omax = np.empty((nz, nx), np.float32); omean = np.empty((nz, nx), np.float32)
     lib = _lib.load()
-    _lib.check(lib.ts2d_project_coronal(int(device), a.ctypes.data, a.size, _GPU_DTYPES[a.dtype.name], nz, ny, nx, sz, sy, sx, base,
-                                        omax.ctypes.data, omean.ctypes.data), 'ts2d_project_coronal')
+    zs = None
+    if zscore:
+        norm = np.empty((2, nz, nx), np.float32); stats = np.empty(4, np.float64); box = np.empty(4, np.int32)
+        _lib.check(lib.ts2d_project_coronal_zscore(int(device), a.ctypes.data, a.size, _GPU_DTYPES[a.dtype.name], nz, ny, nx, sz, sy, sx, base,
+                                                   omax.ctypes.data, omean.ctypes.data, norm.ctypes.data, stats.ctypes.data, box.ctypes.data),
+                   'ts2d_project_coronal_zscore')
+        zs = {'norm': norm, 'stats': tuple(float(v) for v in stats), 'box': tuple(int(v) for v in box), 'shape': (nz, nx)}
+    else:
+        _lib.check(lib.ts2d_project_coronal(int(device), a.ctypes.data, a.size, _GPU_DTYPES[a.dtype.name], nz, ny, nx, sz, sy, sx, base,
+                                            omax.ctypes.data, omean.ctypes.data), 'ts2d_project_coronal')
     sp = tuple(img.spacing[ax] for ax in perm)
     geo = _reoriented_geometry(img, perm, flips)
-    return {m: Image(arr.reshape(nz, 1, nx), sp, geo[0], geo[1], 1, dict(img.meta), img.space) for m, arr in (('max', omax), ('mean', omean))}
+    out = {m: Image(arr.reshape(nz, 1, nx), sp, geo[0], geo[1], 1, dict(img.meta), img.space) for m, arr in (('max', omax), ('mean', omean))}
+    if zs is not None:
+        out['zscore'] = zs
+    return out
 
 
 def _reoriented_geometry(img: Image, perm, flips):

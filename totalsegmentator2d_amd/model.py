@@ -150,6 +150,8 @@ class HIPModel:
             ref = nrrd.read(img) if isinstance(img, str) else img
             from .preprocess import image_to_array
             data, props = image_to_array(ref)
+            if getattr(ref, 'device_zscore', None) is not None:
+                props['device_zscore'] = ref.device_zscore      # z-score done on the device behind the projection (image.py)
             pre = p.configuration_manager.preprocessor_class(verbose=p.verbose)
             data, _, props = pre.run_case_npy(data, None, props, p.plans_manager, p.configuration_manager, p.dataset_json)
             ts['preprocessed'] = time.time()

@@ -77,6 +77,16 @@ def zscore(img: np.ndarray) -> np.ndarray:
     return img
 
 
+def _device_zscore_applies(dz, data, bbox, tf, schemes, use_mask) -> bool:
+    """The device result is nnU-Net's result only if nothing sits between projection and normalisation: identity transpose,
+    crop-to-nonzero = whole image (checked on both sides: the device's non-zero box and the host's bbox), plain z-score on
+    every channel, one channel per projection."""
+    nz, nx = dz['shape']
+    return (list(tf) == [0, 1, 2] and data.shape[1:] == (1, nz, nx) and len(dz['order']) == data.shape[0]
+            and tuple(dz['box']) == (0, nz - 1, 0, nx - 1) and [list(b) for b in bbox] == [[0, 1], [0, nz], [0, nx]]
+            and all(s == 'ZScoreNormalization' for s in schemes[:data.shape[0]]) and not any(use_mask[:data.shape[0]]))
+
+
 class DefaultPreprocessor:
     def __init__(self, verbose: bool = True):
         self.verbose = verbose
@@ -96,7 +106,13 @@ class DefaultPreprocessor:
         new_shape = [int(round(i / j * k)) for i, j, k in zip(original_spacing, target_spacing, data.shape[1:])]
         schemes = getattr(configuration_manager, 'normalization_schemes', None) or ['ZScoreNormalization'] * data.shape[0]
         use_mask = getattr(configuration_manager, 'use_mask_for_norm', None) or [False] * data.shape[0]
+        dz = properties.pop('device_zscore', None)
+        if dz is not None and not _device_zscore_applies(dz, data, bbox, tf, schemes, use_mask):
+            dz = None
         for c in range(data.shape[0]):
+            if dz is not None:          # normalised on the device behind the projection (ts2d_project_coronal_zscore): no host pass
+                data[c, 0] = dz['norm'][dz['order'][c]]
+                continue
             if schemes[c] == 'ZScoreNormalization' and c < len(use_mask) and use_mask[c]:
                 # upstream then takes mean/std inside the nonzero mask only and leaves the outside at 0 - refuse rather than
                 # normalise differently in silence

@@ -100,9 +100,10 @@ class TS2D:
                     and all(n.lower() in ('max', 'mip', 'mean', 'avg') for n in need):
                 # product path: both projections in one pass over the volume on the GPU, reorientation folded into the strides
                 from .image import project_coronal_gpu
-                pr = project_coronal_gpu(input, getattr(model._predictor.device, 'index', 0) or 0)
+                pr = project_coronal_gpu(input, getattr(model._predictor.device, 'index', 0) or 0, zscore=True)
                 for n in need:
                     projections[n] = pr['max' if n.lower() in ('max', 'mip') else 'mean']
+                cache['device_zscore'] = pr['zscore']      # both projections normalised on the device (preprocess.py uses it)
             else:
                 input = reorient_image(input, 'RAI')
             chs = []
@@ -118,6 +119,10 @@ class TS2D:
             projections.update((f"ch{i}", ch) for i, ch in enumerate(split_channels(input)))
         native_2d = input.dimension < 3
         input2d = input if native_2d else reduce_dimensions(input)
+        dz = cache.get('device_zscore')
+        if dz is not None and not native_2d and all(n.lower() in ('max', 'mip', 'mean', 'avg') for _, n in channels):
+            # channel order of THIS model over the (max, mean) planes the device normalised
+            input2d.device_zscore = dict(dz, order=tuple(0 if n.lower() in ('max', 'mip') else 1 for _, n in channels))
         seg = model.apply(input2d)
         if not (collapse or native_2d):
             seg = restore_dimension(seg, input)
