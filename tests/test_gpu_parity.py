@@ -254,7 +254,7 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
 
 
 def test_composed_upsampling_block_matches_the_two_kernel_path_and_the_oracle(monkeypatch):
-    """kernels_upc.h: ConvTranspose2d composed into the "up" half of the next 3x3 conv (parity-specific 2x2 weights over the
+    """kernels_upc.h / kernels_upq.h: ConvTranspose2d composed into the "up" half of the next 3x3 conv (parity-specific 2x2 weights over the
     coarse tensor, nine bias variants for the image border).  Checked against the two-kernel path (TS2D_UPC=0) layer by layer and
     against the torch oracle, with the transposed conv's BIAS blown up so that a wrong border variant cannot hide, on extents
     where some levels compose (complete 8 x 32 tiles) and others do not, one and several tiles per image, BN = 32 and 64."""
@@ -262,7 +262,8 @@ def test_composed_upsampling_block_matches_the_two_kernel_path_and_the_oracle(mo
     from totalsegmentator2d_amd import weights
     runs = ((cases.unet(4, (32, 64, 128, 128), 6, cin=2), 3, 64, 128, 31),        # levels 0-2 compose, level 2 has ONE tile per image
             (cases.unet(3, (64, 64, 128), 5, cin=1), 2, 32, 64, 32),              # BN = 64 at level 0; level 1 (16 x 32) composes
-            (cases.unet(3, (32, 64, 128), 3, cin=1, nconv=1), 1, 256, 256, 33))   # many tiles per image
+            (cases.unet(3, (32, 64, 128), 3, cin=1, nconv=1), 1, 256, 256, 33),   # many tiles per image
+            (cases.unet(4, (32, 64, 128, 256), 4, cin=1), 2, 128, 256, 34))       # Cb = 256 at level 2 (32 x 64): the 512-thread conv3x3_upq, edge tiles on all sides
     for arch, B, H, W, seed in runs:
         sd = weights.synthetic_state_dict(arch, seed)
         for k in sd:

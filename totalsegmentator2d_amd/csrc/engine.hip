@@ -15,6 +15,7 @@
 #include "kernels_s2v2.h"
 #include "kernels_wino.h"
 #include "kernels_upc.h"
+#include "kernels_upq.h"
 #include "kernels_sw.h"
 #include "kernels_project.h"
 
@@ -131,6 +132,7 @@ struct ts2d_engine {
     bool use_p = true;            // plane-layout stride-1 kernel (TS2D_P=0 falls back to conv3x3_f16x3_one)
     bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
     bool use_q = true;            // 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (TS2D_Q=0 falls back to conv3x3_f16x3_p)
+    bool use_upq = true;          // 512-thread double-buffered variant of the composed block on 16 x 32 tiles (TS2D_UPQ=0: conv3x3_upc)
     bool use_upc = true;          // decoder c0 blocks composed with their transposed conv (TS2D_UPC=0 falls back to two kernels)
     unsigned long long* d_prof = nullptr;     // TS2D_DBG=256: in-kernel phase counters, 8 per op (diagnostic)
     std::vector<char> fused_away; // per op of the last run: 1 = its output tensor was not materialised (composed into the next op)
@@ -929,15 +931,29 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             ua.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
             const int grid = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
             const size_t smem_u = std::max((size_t)8 * kUcPlane, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
-            TRY(prof_begin(e, op.name, st)); prof_kernel(e, bn == 64 ? "conv3x3_upc<64>" : "conv3x3_upc<32>");
-            if (bn == 64) {
-                static std::atomic<uint64_t> done64{0};
-                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<64>), done64));
-                hipLaunchKernelGGL(conv3x3_upc<64>, dim3(grid), dim3(kBlock), smem_u, st, ua);
+            auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+            const bool upq = e->use_upq && bn == 64 && up.cin >= 256 && Ht % 16 == 0 &&      // (Cb = 128: no faster than conv3x3_upc, measured)
+                             pow2(Wt / 32) && pow2((Wt / 32) * (Ht / 16)) && xc.scale != nullptr &&
+                             sk.scale != nullptr && up.cin <= 512 && op.cin_skip <= 512;
+            if (upq) {       // 16 x 32 tiles, one 512-thread workgroup per CU, double-buffered staging (kernels_upq.h)
+                ua.tiles_y = Ht / 16; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y;
+                ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
+                const int gridq = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
+                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_upq");
+                static std::atomic<uint64_t> doneq{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upq), doneq));
+                hipLaunchKernelGGL(conv3x3_upq, dim3(gridq), dim3(kUqThreads), kUqLds, st, ua);
             } else {
-                static std::atomic<uint64_t> done32{0};
-                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<32>), done32));
-                hipLaunchKernelGGL(conv3x3_upc<32>, dim3(grid), dim3(kBlock), smem_u, st, ua);
+                TRY(prof_begin(e, op.name, st)); prof_kernel(e, bn == 64 ? "conv3x3_upc<64>" : "conv3x3_upc<32>");
+                if (bn == 64) {
+                    static std::atomic<uint64_t> done64{0};
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<64>), done64));
+                    hipLaunchKernelGGL(conv3x3_upc<64>, dim3(grid), dim3(kBlock), smem_u, st, ua);
+                } else {
+                    static std::atomic<uint64_t> done32{0};
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<32>), done32));
+                    hipLaunchKernelGGL(conv3x3_upc<32>, dim3(grid), dim3(kBlock), smem_u, st, ua);
+                }
             }
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
@@ -1217,6 +1233,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_S2V2")) e->use_s2v2 = getenv("TS2D_S2V2")[0] == '1';
         if (getenv("TS2D_P")) e->use_p = getenv("TS2D_P")[0] == '1';
         if (getenv("TS2D_Q")) e->use_q = getenv("TS2D_Q")[0] == '1';
+        if (getenv("TS2D_UPQ")) e->use_upq = getenv("TS2D_UPQ")[0] == '1';
         if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
         if (getenv("TS2D_WINO")) e->wino_min = atoi(getenv("TS2D_WINO"));

@@ -17,6 +17,9 @@ namespace ts2d {
 // so that no memory operation moves across it.  (Never between an LDS-DMA and the reads of what it wrote.)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// C operand of the first MFMA into a fresh accumulator: the inline constant 0 (zeroing 64 registers per chunk costs 64 VALU issues)
+constexpr f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
 // In-kernel phase stamps (diagnostic runs, TS2D_DBG=256): wave 0 of every workgroup adds the shader-clock cycles between
 // consecutive stamps to slot I of its op's counters (64 sets of 8, picked by block index); slot 7 counts workgroups.  PROF is the pointer (nullptr in production:
 // one scalar compare per stamp).  This is how the serialised epilogue of conv3x3_upc was found (gpurun r2 upc_ph3).
