@@ -16,6 +16,7 @@
 #include "kernels_wino.h"
 #include "kernels_upc.h"
 #include "kernels_upq.h"
+#include "kernels_upc_h.h"
 #include "kernels_sw.h"
 #include "kernels_project.h"
 
@@ -845,7 +846,9 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
 
 // Does the decoder block `op` (3x3 conv over cat(up, skip)) run as ONE kernel together with its transposed conv for this geometry?
 bool upc_applies(const ts2d_engine* e, const Op& op, int B, int H, int W) {
-    if (!op.upc_ok || !e->use_upc || !e->use_one || e->precision != TS2D_PRECISION_F32_SPLIT_F16X3) return false;
+    if (!op.upc_ok || !e->use_upc || !e->use_one || e->precision == TS2D_PRECISION_F32_EXACT) return false;
+    if (e->precision == TS2D_PRECISION_F16 && (op.cin_skip % 32 || e->tensors[e->ops[op.up_idx].src].scale == nullptr || e->tensors[op.skip].scale == nullptr))
+        return false;                       // (the 16-bit kernel walks the skip channels in chunks of 32 and normalises both sources)
     const int Ht = H >> op.level, Wt = W >> op.level;
     if (Ht % 8 || Wt % 32) return false;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
@@ -932,10 +935,20 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const int grid = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
             const size_t smem_u = std::max((size_t)8 * kUcPlane, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
             auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-            const bool upq = e->use_upq && bn == 64 && up.cin >= 256 && Ht % 16 == 0 &&      // (Cb = 128: no faster than conv3x3_upc, measured)
+            const bool upq = !f16 && e->use_upq && bn == 64 && up.cin >= 256 && Ht % 16 == 0 &&      // (Cb = 128: no faster than conv3x3_upc, measured)
                              pow2(Wt / 32) && pow2((Wt / 32) * (Ht / 16)) && xc.scale != nullptr &&
                              sk.scale != nullptr && up.cin <= 512 && op.cin_skip <= 512;
-            if (upq) {       // 16 x 32 tiles, one 512-thread workgroup per CU, double-buffered staging (kernels_upq.h)
+            if (f16) {       // 16-bit mode: fp16 storage, one product (kernels_upc_h.h)
+                const int ks = up.cin % 64 == 0 ? 4 : 2;
+                const size_t smem_h = std::max((size_t)ks * 2 * kUcPlane, (size_t)4 * kUsPlane + (size_t)2 * 9 * 2 * bn * 16);
+                TRY(prof_begin(e, op.name, st)); prof_kernel(e, bn == 64 ? "conv3x3_upc_h<64>" : "conv3x3_upc_h<32>");
+#define TS2D_UPCH(BN_, KS_) do { static std::atomic<uint64_t> done_{0}; \
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h<BN_, KS_>), done_)); \
+                    hipLaunchKernelGGL((conv3x3_upc_h<BN_, KS_>), dim3(grid), dim3(kBlock), smem_h, st, ua); } while (0)
+                if (bn == 64) { if (ks == 4) TS2D_UPCH(64, 4); else TS2D_UPCH(64, 2); }
+                else { if (ks == 4) TS2D_UPCH(32, 4); else TS2D_UPCH(32, 2); }
+#undef TS2D_UPCH
+            } else if (upq) {       // 16 x 32 tiles, one 512-thread workgroup per CU, double-buffered staging (kernels_upq.h)
                 ua.tiles_y = Ht / 16; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y;
                 ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
                 const int gridq = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
