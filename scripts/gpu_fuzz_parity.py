@@ -11,7 +11,32 @@ from oracle import torch_oracle as O
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 worst = {'split': 0.0, 'exact': 0.0}
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+big = len(sys.argv) > 3 and sys.argv[3] == 'big'      # larger extents / wider nets: the 512-thread kernels (conv3x3_f16x3_q, conv3x3_upq), composed blocks
 for t in range(n):
+    if big:
+        ns = int(rng.integers(3, 5))
+        feats = [int(rng.choice([32, 64]))]
+        for i in range(1, ns): feats.append(min(feats[-1] * 2, 256))
+        K = int(rng.integers(1, 27)); cin = int(rng.integers(1, 3))
+        H = 64 * int(rng.integers(1, 5)); W = 128 * int(rng.integers(1, 4)); B = int(rng.integers(1, 4))
+        arch = cases.unet(ns, feats, K, cin=cin, nconv=int(rng.integers(1, 3)))
+        sd = weights.synthetic_state_dict(arch, 500 + t); blob = weights.pack_blob(arch, sd)
+        x = prng.normal_f32(600 + t, 1, (B, cin, H, W))
+        ref = O.unet_forward(arch, sd, x).numpy()
+        with Engine(arch, blob) as e:
+            line = f'{t:2d} big stages={ns} feats={feats} K={K} cin={cin} B={B} {H}x{W}:'
+            for mode in ('split', 'f16'):
+                e.set_precision(mode)
+                e.set_profiling(True)
+                lg, mk = e.forward(x, logits=True, mask=True)
+                kern = sorted(set(e.op_kernels().values()) - {'finalize_stats'})
+                e.set_profiling(False)
+                err = float(np.abs(lg - ref).max())
+                assert err <= (1e-4 if mode == 'split' else 0.2), (line, mode, err)
+                assert np.array_equal(unpack_mask(mk, W), (lg > np.float32(1.5 * 2.0 ** -24)).astype(np.uint8)), (line, mode, 'mask')
+                line += f' {mode} {err:.2e}'
+            print(line, '|', ' '.join(k for k in kern if 'up' in k or '_q' in k or '_p' in k), flush=True)
+        continue
     ns = int(rng.integers(2, 6))
     feats = [32 * int(rng.choice([1, 1, 2])) for _ in range(ns)]
     for i in range(1, ns): feats[i] = max(feats[i], feats[i - 1]) * int(rng.choice([1, 2])) if feats[i - 1] < 256 else feats[i - 1]
