@@ -894,8 +894,15 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const int kp = (op.cin + 1) / 2, nt = op.cout / 32, P = (g.PH * g.PW) << g.lgNIMG;
             const size_t smem = std::max((size_t)P * (2 * kp + 1) * sizeof(float), (size_t)4 * op.cout * 2 * sizeof(float));
             TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_first");
-#define TS2D_FIRST(NT_, KP_) do { if (f16) hipLaunchKernelGGL((conv3x3_first<NT_, KP_, _Float16>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa); \
-                                  else hipLaunchKernelGGL((conv3x3_first<NT_, KP_, float>), dim3(g.n_mtiles), dim3(kBlock), smem, st, fa); } while (0)
+            // complete one-image 256-pixel tiles everywhere: persistent workgroups (4 per CU) with the next tile's patch in flight
+            const bool first_full = g.lgNIMG == 0 && g.lgTH + g.lgTW == 8 && g.lgTW >= 4 && H % (1 << g.lgTH) == 0 && W % (1 << g.lgTW) == 0 &&
+                                    P * 2 * kp <= 4 * kBlock && (size_t)H * W * op.cout * 4 < ((size_t)1 << 31);
+            const int grid_first = first_full ? std::min(g.n_mtiles, e->num_cus * (nt == 1 ? 4 : 2)) : g.n_mtiles;
+#define TS2D_FIRST(NT_, KP_) do { \
+                if (first_full) { if (f16) hipLaunchKernelGGL((conv3x3_first<NT_, KP_, _Float16, true>), dim3(grid_first), dim3(kBlock), smem, st, fa); \
+                                  else hipLaunchKernelGGL((conv3x3_first<NT_, KP_, float, true>), dim3(grid_first), dim3(kBlock), smem, st, fa); } \
+                else { if (f16) hipLaunchKernelGGL((conv3x3_first<NT_, KP_, _Float16, false>), dim3(grid_first), dim3(kBlock), smem, st, fa); \
+                       else hipLaunchKernelGGL((conv3x3_first<NT_, KP_, float, false>), dim3(grid_first), dim3(kBlock), smem, st, fa); } } while (0)
             if (nt == 1 && kp == 1) TS2D_FIRST(1, 1);
             else if (nt == 1 && kp == 2) TS2D_FIRST(1, 2);
             else if (nt == 2 && kp == 1) TS2D_FIRST(2, 1);

@@ -18,17 +18,14 @@ struct FirstArgs {
     int lgTH, lgTW, lgNIMG, tiles_x, tiles_y, n_mtiles, PH, PW;
 };
 
-template <int NT, int KP, typename ST = float>      // NT = Cout / 32 column tiles, KP = ceil(C / 2) channel pairs, ST = output storage
-__global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
+// FULL: every tile is a complete 256-pixel tile inside one image (the engine checks) - the workgroups are persistent (grid < tiles)
+// and carry only the fast epilogue; !FULL: one tile per workgroup, both epilogues (ragged / multi-image test geometries).
+template <int NT, int KP, typename ST = float, bool FULL = false>      // NT = Cout / 32 column tiles, KP = ceil(C / 2) channel pairs, ST = output storage
+__global__ __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 1) void conv3x3_first(const FirstArgs a) {
     constexpr int CP = 2 * KP + 1;               // floats per patch pixel (+1 pad: conflict-free ds_read_b32)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int mtile = blockIdx.x;
     const int TH = 1 << a.lgTH, TW = 1 << a.lgTW, NIMG = 1 << a.lgNIMG;
     const int tpi = a.tiles_x * a.tiles_y;
-    const int grp = mtile / tpi, tin = mtile - grp * tpi;
-    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
-    const int nimg0 = grp << a.lgNIMG;
-    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const int PHW = a.PH * a.PW, P = PHW << a.lgNIMG;
 
@@ -44,19 +41,68 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
                 wr[tap][kp][nt] = c < a.C ? a.w[((size_t)(nt * 32 + r) * a.C + c) * 9 + tap] : 0.f;
             }
 
-    // patch: NCHW planes -> LDS [pixel][2*KP (+pad)], zeros outside the image / beyond C
+    // Persistent workgroups (round 2): a workgroup's life used to be ONE serial chain - weight loads, patch loads, LDS, barrier,
+    // 18 MFMAs, stores - so the layer ran at the latency of that chain times tiles / resident workgroups (0.58 ms for 2.1 GB of
+    // output = 3.6 TB/s; the write-only rate of this pool is 5.3-5.6).  Now the weights are loaded once per workgroup and the NEXT
+    // tile's patch values are in flight (registers) while the current tile computes and stores: 0.58 -> 0.49 ms (FULL variant only:
+    // with both epilogues inside the tile loop hipcc needs > 200 registers).
     const float inv_phw = 1.0f / (float)PHW, inv_pw = 1.0f / (float)a.PW;
-    for (int idx = tid; idx < P * 2 * KP; idx += kBlock) {
-        const int c = idx / P, pp = idx - c * P;                       // plane-major: consecutive threads walk a row
+    constexpr int MAXI = 4;                                   // prefetch registers per thread (P * 2 KP <= 4 * 256: every one-image tile)
+    const bool pf = FULL && P * 2 * KP <= MAXI * kBlock;     // uniform
+    // element idx = tid + k * 256 of a tile's patch (plane-major: consecutive threads walk a row): everything that does not depend
+    // on the tile is computed once - offset relative to the tile origin, LDS slot, packed (il, py, px)
+    int eoff[MAXI], elds[MAXI], epk[MAXI];
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+        const int idx = tid + k * kBlock;
+        const int c = idx / P, pp = idx - c * P;
         const int il = (int)(((float)pp + 0.5f) * inv_phw), rem = pp - il * PHW;
         const int py = (int)(((float)rem + 0.5f) * inv_pw), px = rem - py * a.PW;
-        const int n = nimg0 + il, iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-        float v = 0.f;
-        if (c < a.C && n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-            v = a.x[((size_t)(n * a.C + c) * a.H + iy) * a.W + ix];
-        smem[pp * CP + c] = v;
+        const bool ok = idx < P * 2 * KP && c < a.C;
+        eoff[k] = ((il * a.C + c) * a.H + (py - 1)) * a.W + (px - 1);
+        elds[k] = idx < P * 2 * KP ? pp * CP + c : -1;
+        epk[k] = ok ? (il << 20) | (py << 10) | px : -1;
     }
-    __syncthreads();
+    auto patch_value = [&](int k, int mt_) -> float {
+        const int grp_ = mt_ / tpi, tin_ = mt_ - grp_ * tpi, tyi_ = tin_ / a.tiles_x, txi_ = tin_ - tyi_ * a.tiles_x;
+        const int n0_ = grp_ << a.lgNIMG, y0_ = tyi_ << a.lgTH, x0_ = txi_ << a.lgTW;
+        const int il = epk[k] >> 20, py = (epk[k] >> 10) & 1023, px = epk[k] & 1023;
+        const int iy = y0_ - 1 + py, ix = x0_ - 1 + px;
+        float v = 0.f;
+        if (epk[k] >= 0 && n0_ + il < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            v = a.x[(size_t)((long long)(n0_ * a.C * a.H + y0_) * a.W + x0_ + eoff[k])];
+        return v;
+    };
+    float pvn[MAXI];
+    if (pf) {
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) pvn[k] = patch_value(k, (int)blockIdx.x);
+    }
+    for (int mtile = blockIdx.x; mtile < a.n_mtiles; mtile += gridDim.x) {
+    const int grp = mtile / tpi, tin = mtile - grp * tpi;
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
+    const int nimg0 = grp << a.lgNIMG;
+    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+    if (mtile != (int)blockIdx.x) lds_barrier();             // the previous tile's LDS reads (fragments, statistics) are done
+    if (pf) {
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) if (elds[k] >= 0) smem[elds[k]] = pvn[k];
+    } else {                                                  // (multi-image tiles of tiny test images: loaded in place)
+        for (int idx = tid; idx < P * 2 * KP; idx += kBlock) {
+            const int c = idx / P, pp = idx - c * P;
+            const int il = (int)(((float)pp + 0.5f) * inv_phw), rem = pp - il * PHW;
+            const int py = (int)(((float)rem + 0.5f) * inv_pw), px = rem - py * a.PW;
+            const int n = nimg0 + il, iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+            float v = 0.f;
+            if (c < a.C && n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = a.x[((size_t)(n * a.C + c) * a.H + iy) * a.W + ix];
+            smem[pp * CP + c] = v;
+        }
+    }
+    lds_barrier();
+    if (pf && mtile + (int)gridDim.x < a.n_mtiles) {         // the next tile's patch: in flight during this tile's MFMAs and stores
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) pvn[k] = patch_value(k, mtile + (int)gridDim.x);
+    }
 
     int abase[2];
 #pragma unroll
@@ -90,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
 
     float st_s[NT], st_q[NT];
     // complete one-image tile: one lane offset per 32x32 block + wave-uniform row offsets (see split_epilogue_one)
-    const bool full = a.lgNIMG == 0 && a.lgTH + a.lgTW == 8 && ty0 + TH <= a.H && tx0 + TW <= a.W && a.lgTW >= 4 && nimg0 < a.B;
+    const bool full = FULL || (a.lgNIMG == 0 && a.lgTH + a.lgTW == 8 && ty0 + TH <= a.H && tx0 + TW <= a.W && a.lgTW >= 4 && nimg0 < a.B);
     const size_t img_el = (size_t)a.H * a.W * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0,
                                                        (int)(full ? img_el * sizeof(ST) : 0), 0x00020000);
@@ -104,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
         float ss = 0.f, qq = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            if (full) {
+            if (FULL || full) {
                 const int m0 = 64 * w + 32 * mt + 4 * h;
                 const int oy = ty0 + (m0 >> a.lgTW), ox = tx0 + (m0 & (TW - 1));
                 const unsigned voff = (unsigned)(((oy * a.W + ox) * a.Cout + co) * (int)sizeof(ST));
@@ -117,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
                     v = round_act<ST>(v);
                     ss += v; qq = __builtin_fmaf(v, v, qq);
                 }
-            } else {
+            } else if constexpr (!FULL) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -153,6 +199,7 @@ __global__ __launch_bounds__(kBlock) void conv3x3_first(const FirstArgs a) {
             p[0] = s; p[1] = q;
         }
     }
+    }   // tiles of this workgroup
 }
 
 }  // namespace ts2d
