@@ -10,6 +10,7 @@
 #include "kernels_f16x3_one.h"
 #include "kernels_f16x3_p.h"
 #include "kernels_f16x3_q.h"
+#include "kernels_f16x3_qp.h"
 #include "kernels_first.h"
 #include "kernels_res32.h"
 #include "kernels_s2v2.h"
@@ -132,6 +133,7 @@ struct ts2d_engine {
     int wino_min = 0;             // Winograd kernel for stride-1 blocks with at least this many input channels (TS2D_WINO; 0 = off)
     bool use_p = true;            // plane-layout stride-1 kernel (TS2D_P=0 falls back to conv3x3_f16x3_one)
     bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
+    bool use_qp = true;           // persistent variant of the q kernel (TS2D_QP=0: one workgroup per tile)
     bool use_q = true;            // 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (TS2D_Q=0 falls back to conv3x3_f16x3_p)
     bool use_upq = true;          // 512-thread double-buffered variant of the composed block on 16 x 32 tiles (TS2D_UPQ=0: conv3x3_upc)
     bool use_upc = true;          // decoder c0 blocks composed with their transposed conv (TS2D_UPC=0 falls back to two kernels)
@@ -1132,7 +1134,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
             const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32;
             const bool one_s2 = split && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;
-            const bool qtile = one && e->use_q && bn == 64 && ct_total(op) >= 128 && Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr &&      // (>= 8 chunks: measured)
+            const bool qtile = one && e->use_q && bn == 64 && ct_total(op) >= (e->use_qp ? 64 : 128) && Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr &&      // (the per-tile kernel pays off from 8 chunks on, the persistent one from 4: measured)
                                (op.skip < 0 || e->tensors[op.skip].scale != nullptr) && lg_exact(Wt / 32) >= 0 && lg_exact((Wt / 32) * (Ht / 16)) >= 0;
             if (qtile) {
                 // complete 16 x 32 tiles x 64 columns, normalised sources: one 512-thread workgroup per CU, patch and weights
@@ -1141,6 +1143,13 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 ca.tiles_x = Wt / 32; ca.tiles_y = Ht / 16; ca.n_mtiles = B * ca.tiles_x * ca.tiles_y;
                 ca.lg_tx = lg_exact(ca.tiles_x); ca.lg_tpi = lg_exact(ca.tiles_x * ca.tiles_y);
                 const int gridq = (ca.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
+                const int gridp = 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles));       // one persistent workgroup per CU
+                if (e->use_qp && e->dbg == 0 && gridp < gridq) {
+                    static std::atomic<uint64_t> doneqp{0};
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp), doneqp));
+                    hipLaunchKernelGGL(conv3x3_f16x3_qp, dim3(gridp), dim3(kQThreads), kQpLds, st, ca);
+                    le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp");
+                } else {
 #define TS2D_Q_LAUNCH(D_) do { static std::atomic<uint64_t> doneq_{0}; \
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_q<D_>), doneq_)); \
                     hipLaunchKernelGGL(conv3x3_f16x3_q<D_>, dim3(gridq), dim3(kQThreads), kQLds, st, ca); } while (0)
@@ -1150,6 +1159,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 }
 #undef TS2D_Q_LAUNCH
                 le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_q");
+                }
             } else if (one && e->use_p && bn == 64 && Ht % 8 == 0 && Wt % 32 == 0 && g.lgTH == 3 && g.lgTW == 5) {
                 // complete 8 x 32 tiles x 64 columns: plane layout (conflict-free LDS; same speed as the record layout - measured;
                 // the 32-column variant lost its third workgroup per CU to registers and stays on conv3x3_f16x3_one)
@@ -1252,6 +1262,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_RES")) e->use_res = getenv("TS2D_RES")[0] == '1';
         if (getenv("TS2D_S2V2")) e->use_s2v2 = getenv("TS2D_S2V2")[0] == '1';
         if (getenv("TS2D_P")) e->use_p = getenv("TS2D_P")[0] == '1';
+        if (getenv("TS2D_QP")) e->use_qp = getenv("TS2D_QP")[0] == '1';
         if (getenv("TS2D_Q")) e->use_q = getenv("TS2D_Q")[0] == '1';
         if (getenv("TS2D_UPQ")) e->use_upq = getenv("TS2D_UPQ")[0] == '1';
         if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';

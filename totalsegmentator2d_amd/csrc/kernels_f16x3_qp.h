@@ -1,0 +1,238 @@
+// conv3x3_f16x3_qp: conv3x3_f16x3_q with PERSISTENT workgroups - the pipeline of kernels_f16x3_q.h (patch and weights double-buffered,
+// weights by LDS-DMA, one barrier per chunk) runs over ONE stream of (tile, chunk) items per workgroup instead of being filled and
+// drained for every tile: no synchronous first chunk, no surplus prefetches at the end of a tile, the epilogue of a tile overlaps
+// the staging of the next tile's first chunks.  Same tap order, chunking and per-chunk accumulators: conv outputs bit-identical
+// to conv3x3_f16x3_q / _p / _one.
+//
+// A workgroup (grid = 8 * n_ctiles * m workgroups, one per CU) keeps its XCD lane and its column tile and walks the pixel tiles
+// v = blockIdx.x + k * gridDim.x of the XCD-aware map of the other kernels.  Three pipeline stages per iteration: MFMAs of item i,
+// conversion + weight DMA of item i+1, raw patch / scale / shift loads of item i+2; each stage carries its own (tile, chunk)
+// counter; the in-image test of a staging unit is recomputed from the tile origin (two compares per unit) instead of being held
+// in registers per tile.  LDS: the q kernel's 152064 bytes + 4096 for the statistics exchange (the patch buffers stay busy).
+// Measured (gpurun r2 qp1/qp2): 64 -> 64 at level 1 0.93 (conv3x3_f16x3_p) -> 0.84-0.89 ms, 128 -> 128 0.83 -> 0.78, 256 / 512 channels
+// unchanged (0.76 / 0.74): the gain is the per-tile fill and drain, which weighs less the more chunks a tile has.
+#pragma once
+#include "kernels_f16x3_q.h"
+
+namespace ts2d {
+
+constexpr int kQpRed = kQLds, kQpLds = kQLds + 4096;
+
+__global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs a) {
+    constexpr int BN = 64, NT = 2, MAXU = 3, WTAP = 4 * BN * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+    const int r = lane & 31, h = lane >> 5;
+    const int octi = (lane >> 3) & 1, oct = octi * 8;
+
+    // ---- this workgroup's tiles: virtual block v = blockIdx.x + k * gridDim.x -> (xcd, column tile) fixed, pixel tile mtile0 + k * mstep
+    const int xcd = blockIdx.x & 7, q80 = blockIdx.x >> 3;
+    const int ctile = q80 & (a.n_ctiles - 1), n0col = ctile * BN;
+    const int mtile0 = (q80 >> a.lg_nct) * 8 + xcd, mstep = ((int)(gridDim.x >> 3) >> a.lg_nct) * 8;
+    if (mtile0 >= a.n_mtiles) return;
+    const int ntl = (a.n_mtiles - 1 - mtile0) / mstep + 1;                 // tiles of this workgroup
+    const int nchunks = (a.C0 + a.C1) / 16;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const size_t img_px = (size_t)a.Hin * a.Win;
+    const float* const src1p = a.src1 ? a.src1 : a.src0;
+    const float* const sc1p = a.src1 ? a.sc1 : a.sc0;
+    const float* const sh1p = a.src1 ? a.sh1 : a.sh0;
+
+    // ---- staging units (as conv3x3_f16x3_q): patch pixel pp = 32 (8 it + w) + (lane & 7) + 8 (lane >> 4) -> (py, px), tile-independent
+    int upk[MAXU], lw[MAXU];
+#pragma unroll
+    for (int it = 0; it < MAXU; ++it) {
+        const int pp = 32 * (8 * it + w) + (lane & 7) + 8 * (lane >> 4);
+        const int py = pp / kPPW, px = pp - py * kPPW;
+        upk[it] = pp < kQSlots ? (py << 8) | px : -1;
+        lw[it] = octi * kQPlane + pp * 16;
+    }
+    struct Item { int k, c; };                               // tile number within the workgroup, chunk
+    auto advance = [&](Item& t) {                            // next item of the stream; the last item repeats (loaded / staged, never used)
+        int c = t.c + 1, k = t.k;
+        if (c == nchunks) { c = 0; ++k; }
+        if (k < ntl) { t.k = k; t.c = c; }
+    };
+    auto tile_origin = [&](int k, int& nimg, int& ty0, int& tx0, int& tin) {
+        const int mtile = mtile0 + k * mstep;
+        nimg = mtile >> a.lg_tpi; tin = mtile - nimg * tpi;
+        const int tyi = tin >> a.lg_tx, txi = tin - tyi * a.tiles_x;
+        ty0 = tyi << 4; tx0 = txi << 5;
+    };
+
+    u32x4 pv[MAXU][2];
+    f32x4 nsa, nsb, nta, ntb;
+    unsigned real_pf = 0, real_cv = 0;                       // bit it: unit it of the prefetched / to-be-converted item lies inside the image
+    auto prefetch = [&](const Item& t) {                     // 6 buffer loads + 4 global loads, branch-free
+        int nimg, ty0, tx0, tin;
+        tile_origin(t.k, nimg, ty0, tx0, tin);
+        const int cb0 = t.c * 16;
+        const bool first = cb0 < a.C0;
+        const int cb = first ? cb0 : cb0 - a.C0, C = first ? a.C0 : a.C1;
+        const float* base = (first ? a.src0 : src1p) + (size_t)nimg * img_px * C;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(img_px * C * 4), 0x00020000);
+        unsigned m = 0;
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) {
+            const int iy = ty0 - 1 + (upk[it] >> 8), ix = tx0 - 1 + (upk[it] & 255);
+            const bool in = upk[it] >= 0 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            const unsigned vo = in ? (unsigned)(((iy * a.Win + ix) * C + oct) * 4) : 0x80000000u;
+            pv[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, cb * 4, 0);
+            pv[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16, cb * 4, 0);
+            m |= in ? (1u << it) : 0u;
+        }
+        real_pf = m;
+        const float* ps = (first ? a.sc0 : sc1p) + (size_t)nimg * C + cb + oct;
+        const float* pt = (first ? a.sh0 : sh1p) + (size_t)nimg * C + cb + oct;
+        nsa = *reinterpret_cast<const f32x4*>(ps); nsb = *reinterpret_cast<const f32x4*>(ps + 4);
+        nta = *reinterpret_cast<const f32x4*>(pt); ntb = *reinterpret_cast<const f32x4*>(pt + 4);
+    };
+    auto convert = [&](int it, unsigned char* pb) {          // branch-free arithmetic (a padding pixel stores zeros)
+        f32x4 va = __builtin_bit_cast(f32x4, pv[it][0]), vb = __builtin_bit_cast(f32x4, pv[it][1]);
+        va = va * nsa + nta; vb = vb * nsb + ntb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            va[e] = fmaxf(va[e], va[e] * a.slope);
+            vb[e] = fmaxf(vb[e], vb[e] * a.slope);
+        }
+        uint4 hi, lo;
+        split_hi_lo_8(va, vb, hi, lo);
+        const bool real = (real_cv >> it) & 1u;
+        hi.x = real ? hi.x : 0u; hi.y = real ? hi.y : 0u; hi.z = real ? hi.z : 0u; hi.w = real ? hi.w : 0u;
+        lo.x = real ? lo.x : 0u; lo.y = real ? lo.y : 0u; lo.z = real ? lo.z : 0u; lo.w = real ? lo.w : 0u;
+        if (it < 2 || upk[it] >= 0) {
+            *reinterpret_cast<uint4*>(pb + lw[it]) = hi;
+            *reinterpret_cast<uint4*>(pb + lw[it] + 2 * kQPlane) = lo;
+        }
+    };
+    auto weights_dma = [&](int ch, unsigned char* wb) {     // 36 pieces of 1 KiB; every wave issues exactly 5 (pieces 32..35 twice)
+        const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wph) + ((size_t)ch * a.n_ctiles + ctile) * kQWts + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(wsrc + (w + 8 * j) * 1024, (lds_ptr)(wb + (w + 8 * j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(wsrc + ((w & 3) + 32) * 1024, (lds_ptr)(wb + ((w & 3) + 32) * 1024), 16, 0, 0);
+    };
+
+    unsigned char* const wbuf0 = smem8 + 2 * kQPatch;
+    // ---- fill the pipeline: item 0 staged synchronously (once per workgroup), item 1 requested
+    Item cur{0, 0}, nx1{0, 0}, nx2{0, 0};
+    prefetch(cur);
+    real_cv = real_pf;
+    weights_dma(0, wbuf0);
+#pragma unroll
+    for (int it = 0; it < MAXU; ++it) convert(it, smem8);
+    advance(nx1);
+    nx2 = nx1;
+    prefetch(nx1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    advance(nx2);
+
+    const int abase = h * kQPlane + ((2 * w) * kPPW + r) * 16;
+    const int bbase = h * BN * 16 + r * 16;
+
+    f32x16 acc_t[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
+
+    const int nitems = ntl * nchunks;
+    for (int i = 0; i < nitems; ++i) {
+        const int b = i & 1;
+        const unsigned char* pa = smem8 + b * kQPatch + abase;
+        const unsigned char* pw = wbuf0 + b * kQWts + bbase;
+        unsigned char* pb_next = smem8 + (b ^ 1) * kQPatch;
+        unsigned char* wb_next = wbuf0 + (b ^ 1) * kQWts;
+        real_cv = real_pf;                                   // the registers hold item i+1 (requested one iteration ago)
+
+        f32x16 acc_c[2][NT];
+        half8 fa[2][2][2], fb[2][NT][2];                     // [buffer][tile][hi, lo]
+#define TS2D_LOAD_FRAGS(BUF, TAP) { \
+            constexpr int toff_ = (((TAP) / 3) * kPPW + ((TAP) % 3)) * 16; \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) { \
+                fa[BUF][mt][0] = *reinterpret_cast<const half8*>(pa + mt * kPPW * 16 + toff_); \
+                fa[BUF][mt][1] = *reinterpret_cast<const half8*>(pa + mt * kPPW * 16 + toff_ + 2 * kQPlane); } \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { \
+                fb[BUF][nt][0] = *reinterpret_cast<const half8*>(pw + (TAP) * WTAP + nt * 512); \
+                fb[BUF][nt][1] = *reinterpret_cast<const half8*>(pw + (TAP) * WTAP + nt * 512 + 2 * BN * 16); } }
+#define TS2D_TAP(TAP, EXTRA) { constexpr int cur_ = (TAP) & 1; \
+            if constexpr ((TAP) + 1 < 9) TS2D_LOAD_FRAGS(cur_ ^ 1, (TAP) + 1) \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) \
+                acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur_][mt][1], fb[cur_][nt][0], (TAP) == 0 ? kZero16 : acc_c[mt][nt], 0, 0, 0); \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) \
+                acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur_][mt][0], fb[cur_][nt][1], acc_c[mt][nt], 0, 0, 0); \
+            EXTRA \
+            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) \
+                acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur_][mt][0], fb[cur_][nt][0], acc_c[mt][nt], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0); }
+        TS2D_LOAD_FRAGS(0, 0)
+        // (memory operations of an item: every use of a loaded register first, THEN the weight DMA - kernels_f16x3_q.h)
+        TS2D_TAP(0, convert(0, pb_next);)
+        TS2D_TAP(1, convert(1, pb_next);)
+        TS2D_TAP(2, convert(2, pb_next); prefetch(nx2);)
+        TS2D_TAP(3, weights_dma(nx1.c, wb_next);)
+        TS2D_TAP(4, ) TS2D_TAP(5, ) TS2D_TAP(6, ) TS2D_TAP(7, ) TS2D_TAP(8, )
+#undef TS2D_TAP
+#undef TS2D_LOAD_FRAGS
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
+
+        if (cur.c == nchunks - 1) {                          // (uniform) the tile is complete: bias, store, statistics; the next items' staging is in flight
+            int nimg, ty0, tx0, tin;
+            tile_origin(cur.k, nimg, ty0, tx0, tin);
+            const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
+            const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(a.dst) + (size_t)nimg * img_el, 0, (int)(img_el * 4), 0x00020000);
+            float st_s[NT], st_q[NT], bvs[NT];
+            const float oscale = *a.oscale;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bvs[nt] = a.bias[n0col + nt * 32 + r];       // (both before the first store)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = n0col + nt * 32 + r;
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int oy = ty0 + 2 * w + mt, ox = tx0 + 4 * h;
+                    const unsigned voff = (unsigned)(((oy * a.Wt + ox) * a.Cout + co) * 4);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rowoff = (e & 3) + 8 * (e >> 2);
+                        const unsigned soff = (unsigned)(rowoff * a.Cout * 4);
+                        const float v = __builtin_fmaf(acc_t[mt][nt][e], oscale, bvs[nt]);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
+                        s += v; q = __builtin_fmaf(v, v, q);
+                        acc_t[mt][nt][e] = 0.f;
+                    }
+                }
+                st_s[nt] = s; st_q[nt] = q;
+            }
+            float* red = reinterpret_cast<float*>(smem8 + kQpRed);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float s = st_s[nt], q = st_q[nt];
+                s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+                if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
+            }
+            lds_barrier();
+            if (tid < BN) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
+                float* p = a.part + ((size_t)(nimg * tpi + tin) * a.Cout + n0col + tid) * 2;
+                p[0] = s; p[1] = q;
+            }
+            // (the next use of `red` is a whole tile away: the per-item barriers below order it)
+        }
+        advance(cur); advance(nx1); advance(nx2);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+}  // namespace ts2d
