@@ -142,8 +142,10 @@ int ts2d_engine_tiled_inf_flag(const ts2d_engine* e);
  *              (0 = int16, 1 = uint8, 2 = float32, 3 = uint16, 4 = int32)
  *   nz, ny, nx extents of the REORIENTED view [z][y][x] (DICOMOrient 'RAI'); sz, sy, sx its signed ELEMENT strides and `base` the
  *              element offset of view[0][0][0] in the buffer (so axis flips / permutations need no host copy)
- *   out_max, out_mean  host [nz][nx] float32: projections along y.  Integer volumes: the mean is the exact sum divided with
- *              truncation back to the integer type (ITK behaviour), then converted to float.  Synchronous. */
+ *   out_max, out_mean  host [nz][nx] float32: projections along y.  The mean is real-valued for every input type: the sum in index
+ *              order (exact for integer volumes) divided in double, rounded once to float - ITK's MeanProjectionImageFilter followed by
+ *              the reference's Cast to Float32 (ts2d/tool.py:182-185); the reference's pre-projected sample assets pin it
+ *              (oracle/input_oracle.py).  Synchronous. */
 int ts2d_project_coronal(int device, const void* volume, size_t n_elems, int dtype, int nz, int ny, int nx, long long sz,
                          long long sy, long long sx, long long base, float* out_max, float* out_mean);
 

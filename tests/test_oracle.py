@@ -128,3 +128,68 @@ def test_torch_oracle_sliding_window_goldens(name, order):
     g = golden(name)['logits_f16' if order == 'float' else 'logits_f16_half']
     assert out.dtype == np.float16 and out.shape == g.shape
     assert np.abs(out.astype(np.float32) - g.astype(np.float32)).max() <= 8e-3   # <= a couple of fp16 ulps at |x| ~ 4
+
+
+def test_mean_projection_is_pinned_by_the_reference_assets():
+    """The reference's pre-projected sample inputs ARE outputs of ``TS2D._project`` (tool.py:152-160,182-185): channel 1 (maximum
+    of an integer CT) is integer-valued, channel 0 (mean) is exactly double(S) / n for an integer S - n = 269 coronal slices
+    (403.5 mm / 1.5 mm, the collapsed axis of sample_s0332) resp. 261 (sample_s0616, stored before the Float32 cast).  This pins
+    oracle/input_oracle.py:project (real-valued mean) - and rules out a mean truncated to the integer input type."""
+    from oracle import input_oracle as IO
+    from totalsegmentator2d_amd import nrrd
+    a = nrrd.read(os.path.join(GOLDEN, 'assets', 'sample_s0332.nrrd'))
+    assert a.array.dtype == np.float32 and round(a.spacing[1] / 1.5) == 269
+    c0, c1 = a.array[..., 0].ravel(), a.array[..., 1].ravel()
+    assert np.array_equal(c1, np.round(c1)) and np.mean(c0 != np.round(c0)) > 0.99
+    S = np.round(c0.astype(np.float64) * 269)
+    assert np.array_equal((S / 269.0).astype(np.float32), c0)                       # float32(double(S) / 269), every pixel
+    b = nrrd.read(os.path.join(GOLDEN, 'assets', 'sample_s0616.nrrd'))
+    assert b.array.dtype == np.float64
+    d0, d1 = b.array[..., 0].ravel(), b.array[..., 1].ravel()
+    assert np.array_equal(d1, np.round(d1)) and np.mean(d0 != np.round(d0)) > 0.99
+    S = np.round(d0 * 261)
+    assert np.array_equal(S / 261.0, d0)                                            # double(S) / 261, every pixel
+    # the oracle reproduces that arithmetic on an integer volume with the same slice count: a (z, y, x) stack of 261 slices
+    rng = np.random.default_rng(7)
+    vol = rng.integers(-1024, 3000, (6, 261, 5)).astype(np.int16)
+    m = IO.project(vol, 'mean', 1)
+    assert m.dtype == np.float64 and np.array_equal(m, vol.sum(axis=1, dtype=np.int64) / 261.0)
+    assert np.array_equal(IO.project_f32(vol, 'mean', 1), (vol.sum(axis=1, dtype=np.int64) / 261.0).astype(np.float32))
+    assert np.array_equal(IO.project(vol, 'max', 1), vol.max(axis=1))
+
+
+def test_host_projection_equals_input_oracle():
+    """Product host code (image.reorient_image + image.project + Float32 cast) against the independent restatement in oracle/,
+    on the reference's 3-D sample (int16, flipped x / y) and on float / uint8 volumes with permuted axes."""
+    from oracle import input_oracle as IO
+    from totalsegmentator2d_amd import image, nrrd
+    rng = np.random.default_rng(3)
+    vols = [nrrd.read(os.path.join(GOLDEN, 'assets', 'sample_s0521.nrrd')),
+            nrrd.Image(rng.normal(0, 300, (40, 33, 50)).astype(np.float32), (1.0, 2.0, 3.0), (5.0, -7.0, 11.0),
+                       (0.0, -1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, -1.0), 1, {}, 'left-posterior-superior'),
+            nrrd.Image(rng.integers(0, 255, (20, 16, 24)).astype(np.uint8), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0),
+                       (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0), 1, {}, None)]
+    for vol in vols:
+        ref = IO.coronal_projections_f32(vol.array, vol.direction)
+        r = image.reorient_image(vol)
+        for mode in ('max', 'mean'):
+            got = image.cast(image.project(r, mode, 'coronal'), np.float32).array[:, 0, :]
+            assert got.dtype == np.float32 and np.array_equal(got, ref[mode]), mode
+    x = rng.normal(-300, 250, (64, 48)).astype(np.float32)
+    from totalsegmentator2d_amd import preprocess
+    assert np.array_equal(preprocess.zscore(x), IO.zscore(x))
+
+
+def test_preprocessor_properties_carry_the_sitk_geometry():
+    """``properties['sitk_stuff']`` holds spacing / origin / direction in SimpleITK order - what upstream's SimpleITK writer reads
+    when the reference's unchanged ``export_prediction_from_logits`` (prediction_worker.py:215-221) consumes these properties."""
+    from totalsegmentator2d_amd import nrrd, preprocess
+    fp = os.path.join(GOLDEN, 'assets', 'sample_s0616.nrrd')
+    img = nrrd.read(fp)
+    _, props = preprocess.read_images([fp])
+    st = props['sitk_stuff']
+    assert set(st) >= {'spacing', 'origin', 'direction', 'files'} and st['files'] == [fp]
+    assert st['spacing'] == tuple(img.spacing) and len(st['spacing']) == 2 and len(st['origin']) == 2 and len(st['direction']) == 4
+    assert props['spacing'] == (999.0, img.spacing[1], img.spacing[0])            # nnU-Net order beside it
+    _, p2 = preprocess.image_to_array(img)
+    assert p2['sitk_stuff']['direction'] == tuple(img.direction) and p2['sitk_stuff']['files'] == []

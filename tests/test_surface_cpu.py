@@ -36,7 +36,9 @@ def test_projection_and_dimension_round_trip():
     mn = image.cast(image.project(v, 'mean', 'coronal'), np.float32)
     assert mx.size == (53, 1, 133) and mn.array.dtype == np.float32
     assert np.array_equal(mx.array[:, 0, :], v.array.max(axis=1))
-    assert np.array_equal(mn.array[:, 0, :], np.trunc(v.array.astype(np.float64).mean(axis=1)).astype(np.float32))
+    from oracle import input_oracle as IO                              # the checker: real-valued mean (double sum / n, then Float32)
+    assert np.array_equal(mn.array[:, 0, :], IO.project_f32(v.array, 'mean', 1))
+    assert np.mean(mn.array != np.round(mn.array)) > 0.9              # NOT truncated back to int16
     two = image.reduce_dimensions(image.compose([mn, image.cast(mx, np.float32)]))
     assert two.dimension == 2 and two.size == (53, 133) and two.components == 2 and two.spacing == (1.5, 1.5)
     back = image.restore_dimension(two, mx)

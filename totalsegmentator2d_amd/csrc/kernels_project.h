@@ -21,10 +21,10 @@ __global__ void project_coronal(const T* __restrict__ vol, int nz, int ny, int n
         float mx = (float)p[0]; double s = 0.0;
         for (int y = 0; y < ny; ++y) { const float v = (float)p[y * sy]; mx = v > mx ? v : mx; s += (double)v; }
         out_max[i] = mx; out_mean[i] = (float)(s / ny);
-    } else {                                                       // integer volume: exact sum, truncating division
+    } else {                                                       // integer volume: exact sum, real-valued mean
         long long mx = (long long)p[0], s = 0;
         for (int y = 0; y < ny; ++y) { const long long v = (long long)p[y * sy]; mx = v > mx ? v : mx; s += v; }
-        out_max[i] = (float)mx; out_mean[i] = (float)(T)(s / ny);
+        out_max[i] = (float)mx; out_mean[i] = (float)((double)s / (double)ny);
     }
 }
 

@@ -65,8 +65,9 @@ def reorient_image(img: Image, orient: str = 'RAI') -> Image:
 
 def project(img: Image, mode: str = 'max', axis=-1) -> Image:
     """``sitk.{Maximum,Minimum,Mean}ProjectionImageFilter`` along ``axis``: the projected axis keeps size 1 and its
-    origin (reference image.py:97-100).  [UPSTREAM-RECALL] ITK casts the mean back to the input pixel type
-    (truncation for integer volumes); the reference casts to Float32 afterwards (tool.py:182-185)."""
+    origin (reference image.py:97-100).  The mean is REAL-valued (float64: ITK accumulates and divides in double), also for
+    integer volumes - pinned by the reference's own pre-projected assets (``sample_s0332`` / ``sample_s0616``: channel 0 is
+    exactly ``double(sum) / n``; tests/test_oracle.py); the reference casts to Float32 afterwards (tool.py:182-185)."""
     ax = axis_name_to_index(axis) if isinstance(axis, str) else list(range(img.dimension))[axis]
     mode = str(mode).lower().strip()
     npax = _np_axis(img, ax)
@@ -77,10 +78,13 @@ def project(img: Image, mode: str = 'max', axis=-1) -> Image:
         r = a.min(axis=npax, keepdims=True)
     elif mode in ('avg', 'mean'):
         if np.issubdtype(a.dtype, np.integer):      # exact integer sum (15x faster than a float64 copy of a CT volume)
-            m = a.sum(axis=npax, keepdims=True, dtype=np.int64) / a.shape[npax]
-            r = np.trunc(m).astype(a.dtype)
-        else:
-            r = (a.astype(np.float64).sum(axis=npax, keepdims=True) / a.shape[npax]).astype(a.dtype)
+            r = a.sum(axis=npax, keepdims=True, dtype=np.int64).astype(np.float64) / np.float64(a.shape[npax])
+        else:                                       # ITK's accumulator: slices added in index order, in double
+            v = np.moveaxis(a, npax, 0)
+            acc = np.zeros(v.shape[1:], np.float64)
+            for k in range(v.shape[0]):
+                acc += v[k]
+            r = np.expand_dims(acc / np.float64(v.shape[0]), npax)
     else:
         raise RuntimeError(f"Unsupported filter mode: {mode}")
     return Image(np.ascontiguousarray(r), img.spacing, img.origin, img.direction, img.components, dict(img.meta), img.space)

@@ -15,6 +15,16 @@ import numpy as np
 from . import nrrd
 
 
+def sitk_stuff(img, files=()) -> dict:
+    """``properties['sitk_stuff']`` as upstream's ``SimpleITKIO.read_images`` fills it [UPSTREAM-RECALL]: the geometry of the
+    FIRST input image in SimpleITK order (x, y[, z]; direction flattened row-major).  Upstream's ``SimpleITKIO.write_seg``
+    reads exactly these three keys back when the reference's unchanged exporter (``export_prediction_from_logits``,
+    ``ts2d/core/inference/prediction_worker.py:215-221``) writes the result of THIS preprocessor's properties (INTEGRATION.md
+    section 1)."""
+    return {'spacing': tuple(float(v) for v in img.spacing), 'origin': tuple(float(v) for v in img.origin),
+            'direction': tuple(float(v) for v in img.direction), 'files': list(files)}
+
+
 def image_to_array(img) -> Tuple[np.ndarray, dict]:
     """One in-memory image -> (``[c, z, y, x]`` float32, properties); 2-D images get a unit z axis and nnU-Net's
     ``999`` pseudo-spacing."""
@@ -28,13 +38,13 @@ def image_to_array(img) -> Tuple[np.ndarray, dict]:
         sp = (float(img.spacing[2]), float(img.spacing[1]), float(img.spacing[0]))
     else:
         raise RuntimeError(f"unsupported image dimension {img.dimension}")
-    return a.astype(np.float32), {'spacing': sp, 'sitk_stuff': {'files': []}}
+    return a.astype(np.float32), {'spacing': sp, 'sitk_stuff': sitk_stuff(img)}
 
 
 def read_images(files: Sequence[str]) -> Tuple[np.ndarray, dict]:
     """The fork's reader for one multi-component 2-D file (reference ``ts2d/tool.py:160,170-172`` hands the model ONE
     vector image): ``[y, x, c]`` -> ``[c, 1, y, x]``; spacing reported nnU-Net style ``(999, sy, sx)`` for 2-D."""
-    arrs, spacing = [], None
+    arrs, spacing, stuff = [], None, None
     for fp in files:
         img = nrrd.read(fp)
         a = np.asarray(img.array)
@@ -48,9 +58,10 @@ def read_images(files: Sequence[str]) -> Tuple[np.ndarray, dict]:
         else:
             raise RuntimeError(f"unsupported image dimension {img.dimension} in {fp}")
         arrs.append(a)
-        spacing = sp
+        if stuff is None:                       # upstream keeps the first image's geometry (and checks the others against it)
+            spacing, stuff = sp, sitk_stuff(img, files)
     data = np.concatenate(arrs, 0).astype(np.float32)
-    return data, {'spacing': spacing, 'sitk_stuff': {'files': list(files)}}
+    return data, {'spacing': spacing, 'sitk_stuff': stuff}
 
 
 def crop_to_nonzero(data: np.ndarray):
