@@ -3,7 +3,11 @@
 sub-model (K=18), fp32).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or plain
+     `python bench.py --gpus N`: with no WORLD_SIZE in the environment the script starts that launcher itself as a CHILD process -
+     one rank per GPU, the reference's counterpart being its `mp.Pool` of workers, ts2d/core/inference/predictor.py:79-86 -
+     and relays rank 0's line and the exit code.  TS2D_BENCH_DRYRUN=gloo runs the N-rank control path on the CPU: process group,
+     weight-blob broadcast, slice sharding, time reduction; no GPU call.)
 
 One "step" = one forward pass of the hot path (the whole PlainConvUNet, input NCHW -> fp32 logits NCHW + packed masks)
 over one batch of 64 synthetic slices per GPU, inputs already resident in HBM.  Slices shard over ranks with no
@@ -142,18 +146,76 @@ def run_config3(args, torch, dev, local_rank):
     print(json.dumps(out), flush=True)
 
 
-def run_config4(args, torch, dev, engine, rank, world, total, seed=0, batch=64):
+def run_config4(args, torch, dev, engine, rank, world, total, seed=0, batch=64, reduce=True):
     """BASELINE config 4 on this rank: its contiguous block of the `total`-slice stream (generated on the device beforehand)."""
     from totalsegmentator2d_amd import parallel
     engine.set_precision(args.precision)
-    lo, hi, _, _ = parallel.run_slice_stream(engine, seed, min(total, 2 * batch * world), rank, world, batch=batch, keep_masks=False)   # warm-up
-    if world > 1 or os.environ.get('TS2D_FORCE_DIST') == '1':
-        import torch.distributed as dist
-        dist.barrier()
+    werr = None
+    try:
+        parallel.run_slice_stream(engine, seed, min(total, 2 * batch * world), rank, world, batch=batch, keep_masks=False)   # warm-up
+    except Exception as ex:                                                # noqa: BLE001
+        werr = f'{type(ex).__name__}: {ex}'
+    # the barrier in front of the timed region doubles as the agreement that every rank got through its warm-up: a rank that
+    # failed still reaches it, and then ALL ranks raise (nobody is left waiting in a collective)
+    if parallel.max_over_ranks(1.0 if werr else 0.0) > 0:
+        raise RuntimeError(werr or 'config-4 warm-up failed on another rank')
     lo, hi, masks, dt = parallel.run_slice_stream(engine, seed, total, rank, world, batch=batch, keep_masks=True)
-    el = parallel.max_over_ranks(dt)
+    el = parallel.max_over_ranks(dt) if reduce else dt            # reduce=False: the caller reduces (after agreeing that no rank failed)
+    biggest = max(b - a for a, b in (parallel.shard_range(total, r, world) for r in range(world)))     # remainder ranks hold one more
     return {'slices': total, 'block_of_rank0': [lo, hi], 'seconds': round(el, 4), 'value': round(total / el, 2), 'unit': 'slices/s',
-            'batch': batch, 'mask_words_kept': int(masks.numel()) if masks is not None else 0}
+            'batch': batch, 'steps': (biggest + batch - 1) // batch, 'mask_words_kept': int(masks.numel()) if masks is not None else 0}
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start `torch.distributed.run` with N ranks of this script as a child
+    process (never os.exec*: nothing here has touched the GPU, but the child is still the safe form), stdout / stderr inherited so
+    rank 0's single JSON line goes straight through; returns the child's exit code."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // n)))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')            # dmabuf IPC: RCCL across processes needs it on this pool
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, backend: str):
+    """TS2D_BENCH_DRYRUN=<backend> (gloo): the multi-rank CONTROL path of this script without a GPU - process group, weight
+    broadcast (the host blob instead of the device arena), the config-4 slice blocks, the barrier + max-over-ranks reduction of
+    the timed region - on a narrow net; rank 0 prints one line with `n_gpus` = world."""
+    import torch.distributed as dist
+    from totalsegmentator2d_amd import parallel, weights
+    from totalsegmentator2d_amd.arch import UNetArch
+    rank, _, world = parallel.env_rank_world()
+    parallel.init_process_group(backend)
+    arch = UNetArch.canonical(input_channels=2, num_classes=2, n_stages=2, base=32, max_features=32)
+    blob = weights.pack_blob(arch, weights.synthetic_state_dict(arch, seed=1)) if rank == 0 else None
+    got = parallel.broadcast_blob(blob, arch.n_params(), src=0)
+    lo, hi = parallel.shard_range(10000, rank, world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))                                # "K steps": rank r takes r + 1 ticks, the max is reported
+    dist.barrier()
+    el = parallel.max_over_ranks(time.perf_counter() - t0)
+    sizes = [0] * world
+    import torch
+    t = torch.zeros(world, dtype=torch.int64); t[rank] = hi - lo
+    dist.all_reduce(t)
+    sizes = [int(v) for v in t]
+    if rank == 0:
+        print(json.dumps({'metric': '2-ch 512x512 slices/sec', 'value': None, 'unit': 'slices/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'dry_run': backend, 'blob_floats': int(got.size), 'blob_sum': float(np.float64(got.sum())),
+                          'stream_blocks': sizes, 'stream_steps': (max(sizes) + args.batch - 1) // args.batch,
+                          'elapsed_max_s': round(el, 4)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -176,6 +238,13 @@ def main():
     if args.precision is None:
         args.precision = 'f16' if args.workload == 'config3' else 'split'
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # not under a launcher: start one (child process), relay its exit code; nothing below runs in this process
+        raise SystemExit(self_launch(args.gpus))
+    if os.environ.get('TS2D_BENCH_DRYRUN'):
+        dry_run(args, os.environ['TS2D_BENCH_DRYRUN'])
+        return
+
     import torch
     import torch.distributed as dist
     from totalsegmentator2d_amd import parallel, weights
@@ -185,7 +254,7 @@ def main():
     rank, local_rank, world = parallel.env_rank_world()
     if world != args.gpus:
         if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     multi = world > 1 or os.environ.get('TS2D_FORCE_DIST') == '1'      # the flag rehearses the RCCL path on one GPU
     if multi:
         parallel.init_process_group('nccl')
@@ -229,7 +298,7 @@ def main():
         if rank == 0:
             work = arch.work(H, W)
             out = {'metric': '2-ch 512x512 slices/sec', 'value': r4['value'], 'unit': 'slices/s', 'n_gpus': world,
-                   'steps': (total // world + B - 1) // B, 'warmup': 2, 'ms_per_step': round(r4['seconds'] / max(1, (total // world + B - 1) // B) * 1e3, 3),
+                   'steps': r4['steps'], 'warmup': 2, 'ms_per_step': round(r4['seconds'] / max(1, r4['steps']) * 1e3, 3),
                    'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                    'dtype': 'f32 storage/accumulate, products as 3x fp16-split MFMA (f16x3)' if args.precision == 'split' else args.precision,
                    'data': 'synthetic',
@@ -290,7 +359,19 @@ def main():
     if world > 1:            # config 4 on the same ranks (outside the timed region above): 10k-slice stream, contiguous blocks
         if profile:
             engine.set_profiling(False)
-        stream_res = run_config4(args, torch, dev, engine, rank, world, 10000, batch=B)
+        # Isolated from the primary result: a failure on ANY rank is agreed on by all ranks (one max-reduce of a flag, so no rank
+        # waits in a collective the failed one never reaches) and reported as stream_10k.error; the config-2 line is printed either way.
+        err = None
+        try:
+            stream_res = run_config4(args, torch, dev, engine, rank, world, 10000, batch=B, reduce=False)
+        except Exception as ex:                                            # noqa: BLE001 - reported, not hidden
+            err = f'{type(ex).__name__}: {ex}'
+        failed = parallel.max_over_ranks(1.0 if err else 0.0) > 0
+        if failed:
+            stream_res = {'error': err or 'failed on another rank'}
+        else:
+            el4 = parallel.max_over_ranks(stream_res['seconds'])
+            stream_res.update(seconds=round(el4, 4), value=round(10000 / el4, 2))
 
     if rank == 0:
         work = arch.work(H, W)

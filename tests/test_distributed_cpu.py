@@ -52,3 +52,27 @@ def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / 'rank0.txt').read_text() == '0 5' and (tmp_path / 'rank1.txt').read_text() == '5 10'
+
+
+@pytest.mark.parametrize('n', [2, 3])
+def test_bench_self_launches_n_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it (the driver's command): the script starts torch.distributed.run
+    itself as a child, rank 0 prints ONE JSON line, the exit code is relayed.  TS2D_BENCH_DRYRUN=gloo keeps it on the CPU: process
+    group, weight-blob broadcast, config-4 slice blocks (remainder ranks hold one slice more), max-over-ranks time."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(TS2D_BENCH_DRYRUN='gloo', OMP_NUM_THREADS='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '3', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == n and out['steps'] == 3 and out['warmup'] == 1 and out['dry_run'] == 'gloo'
+    blocks = [hi - lo for lo, hi in (parallel.shard_range(10000, k, n) for k in range(n))]
+    assert out['stream_blocks'] == blocks and out['stream_steps'] == (max(blocks) + 63) // 64
+    assert out['elapsed_max_s'] >= 0.01 * n                      # the slowest rank's time is the one reported
+    # a failing child's exit code comes back (unknown flag -> argparse exits 2 in every rank)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--no-such-flag'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
