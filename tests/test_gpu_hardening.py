@@ -47,6 +47,52 @@ def test_weights_spanning_twenty_binades_in_one_layer():
     assert np.isfinite(lg).all() and _rel_err(lg, ref) <= 1e-4
 
 
+def _wide_case():
+    """2 x 128 x 128 through a 5-stage net: every statistics-producing kernel family runs (first layer, resident 32 -> 32, the
+    persistent q pipeline at levels 1-2, 512-thread stride 2, composed decoder entries incl. the upq form, generic kernels and
+    split-K at the deep levels)."""
+    arch = cases.unet(5, (32, 64, 128, 256, 512), 6)
+    sd = weights.synthetic_state_dict(arch, 62)
+    x = cases.make_input(arch, 2, 128, 128, 62)
+    return arch, sd, x
+
+
+@pytest.mark.parametrize('gain', [100.0, 1000.0])
+def test_large_conv_biases_are_dead_under_instance_norm(gain):
+    """a conv bias is removed again by the InstanceNorm behind it, so blowing the biases up by 100x / 1000x
+    (|mean| / sigma of the raw conv output ~ 1 ... 30) barely moves the oracle's logits - and must not move the engine's: the
+    per-tile statistics are SHIFTED sums around a pivot taken from the tile (kernels.h), not sum(v) / sum(v^2) of the biased values."""
+    arch, sd, x = _wide_case()
+    big = {k: (v * np.float32(gain) if k.endswith('conv.bias') else v) for k, v in sd.items()}
+    ref = O.unet_forward(arch, big, x).numpy()
+    base = O.unet_forward(arch, sd, x).numpy()
+    assert np.abs(ref - base).max() <= 1e-3 * max(1.0, gain / 100.0)          # the oracle itself: the bias is (almost) dead
+    with Engine(arch, weights.pack_blob(arch, big)) as e:
+        for mode in ('split', 'exact'):
+            e.set_precision(mode)
+            lg, _ = e.forward(x)
+            assert np.isfinite(lg).all() and _rel_err(lg, ref) <= 1e-4, (mode, gain, _rel_err(lg, ref))
+
+
+def test_input_offset_puts_the_mean_far_above_sigma_at_the_first_layer():
+    """A network input with an offset of 50 sigma gives the first conv's raw output |mean| / sigma of 0 ... 35 per channel (the
+    same happens to any layer whose input statistics drift): torch normalises with mean first, then sum((x - mean)^2).  The
+    normalised activation of enc0.c0 and the logits must follow the oracle."""
+    arch, sd, x = _wide_case()
+    xo = (x + np.float32(50.0)).astype(np.float32)
+    ref, inter = O.unet_forward(arch, sd, xo, return_intermediates=True)
+    raw = O.F.conv2d(O._t(xo), O._t(sd['encoder.stages.0.0.convs.0.conv.weight']), O._t(sd['encoder.stages.0.0.convs.0.conv.bias']), padding=1).numpy()
+    ratio = np.abs(raw.mean(axis=(2, 3))) / raw.std(axis=(2, 3))
+    assert ratio.max() >= 25.0                                                 # the regime this test is about
+    with Engine(arch, weights.pack_blob(arch, sd)) as e:
+        for mode in ('split', 'exact'):
+            e.set_precision(mode)
+            lg, _ = e.forward(xo)
+            a0 = e.debug_tensor('enc0.c0')
+            assert np.abs(a0 - inter['enc0.c0'].numpy()).max() <= 3e-5, mode
+            assert np.isfinite(lg).all() and _rel_err(lg, ref.numpy()) <= 1e-4, (mode, _rel_err(lg, ref.numpy()))
+
+
 def test_overflowing_transposed_conv_output_is_an_error_naming_the_layer(monkeypatch):
     arch, sd, x = _case()
     blob_ok = weights.pack_blob(arch, sd)

@@ -391,22 +391,3 @@ def test_config3_full_model_set_batch128_f16():
     for mid, (a, b, m) in merged_rows.items():
         assert torch.equal(merged[:, a:b], m)
     assert [merged_rows[m][0] for m in sorted(merged_rows)] == [0, 18, 41, 65, 91]       # cardiac, muscles, organs, ribs, vertebrae
-
-
-def test_winograd_kernel_parity(monkeypatch):
-    """conv3x3_wino (Winograd F(2x2,3x3) on the split path; kernels_wino.h) is kept as an OPT-IN experiment (TS2D_WINO=<min input
-    channels>): its arithmetic stays inside the fp32 parity tolerance, but on MI355X it measured ~20 % slower than the direct
-    kernel.  Parity of the opt-in path on a net whose level-1/2 blocks qualify (64 / 128 channels)."""
-    from oracle import torch_oracle as O
-    arch = cases.unet(3, (32, 64, 128), 6)
-    sd, blob = blob_for(arch, 71)
-    x = cases.make_input(arch, 2, 64, 128, 71)
-    monkeypatch.setenv('TS2D_WINO', '64')
-    with Engine(arch, blob) as e:
-        lg, _ = e.forward(x)
-        names = ['enc1.c1', 'enc2.c1', 'dec1.c0', 'dec1.c1']
-        t = {n: e.debug_tensor(n) for n in names}
-    ref, inter = O.unet_forward(arch, sd, x, return_intermediates=True)
-    assert np.abs(lg - ref.numpy()).max() <= TOL
-    for n in names:
-        assert np.abs(t[n] - inter[n].numpy()).max() <= TOL, n

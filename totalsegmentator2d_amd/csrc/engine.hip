@@ -8,13 +8,10 @@
 #include "kernels_h32.h"
 #include "kernels_head.h"
 #include "kernels_f16x3_one.h"
-#include "kernels_f16x3_p.h"
-#include "kernels_f16x3_q.h"
 #include "kernels_f16x3_qp.h"
 #include "kernels_first.h"
 #include "kernels_res32.h"
 #include "kernels_s2v2.h"
-#include "kernels_wino.h"
 #include "kernels_upc.h"
 #include "kernels_upq.h"
 #include "kernels_upc_h.h"
@@ -74,10 +71,7 @@ struct Op {
     bool h32_ok = false;
     size_t dev_ws = 0;            // offset (floats) of 1 / (power-of-two pre-scale of the split weights)
     size_t dev_wp = 0;            // offset (floats) of the split-fp16 weights in plane order [chunk16][column tile][tap][hi,lo][h][column][8 halves]
-                                  // (conv3x3_f16x3_p; stride-1 split_ok convs)
-    bool wino_ok = false;         // stride-1 block eligible for the Winograd F(2x2,3x3) kernel (kernels_wino.h)
-    size_t dev_wu = 0;            // offset (floats) of U = G g G^T, split fp16: [chunk16][column tile 64][position 16][hi,lo][h][column][8 halves]
-    size_t dev_wus = 0;           // offset (floats) of 1 / (power-of-two pre-scale of U)
+                                  // (conv3x3_f16x3_qp; stride-1 split_ok convs)
     bool s2v2_ok = false;         // stride-2 block: 512-thread kernel of kernels_s2v2.h
     size_t dev_w2 = 0;            // offset (floats) of its weight image [chunk16][column tile][tap][hi,lo][h][column][8 halves]
     int bn2 = 0;                  // its column tile (128 or 64)
@@ -130,11 +124,8 @@ struct ts2d_engine {
     bool use_h32 = true;          // precision mode f16: 32-channel-chunk kernel (TS2D_H32=0 falls back to the 16-channel one)
     bool use_one = true;          // one-image-tile split kernel (TS2D_ONE=0 falls back to the generic one)
     int dbg = 0;                  // TS2D_DBG: timing ablations (diagnostic runs only)
-    int wino_min = 0;             // Winograd kernel for stride-1 blocks with at least this many input channels (TS2D_WINO; 0 = off)
-    bool use_p = true;            // plane-layout stride-1 kernel (TS2D_P=0 falls back to conv3x3_f16x3_one)
     bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
-    bool use_qp = true;           // persistent variant of the q kernel (TS2D_QP=0: one workgroup per tile)
-    bool use_q = true;            // 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (TS2D_Q=0 falls back to conv3x3_f16x3_p)
+    bool use_q = true;            // persistent 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (TS2D_Q=0 falls back to conv3x3_f16x3_one)
     bool use_upq = true;          // 512-thread double-buffered variant of the composed block on 16 x 32 tiles (TS2D_UPQ=0: conv3x3_upc)
     bool use_upc = true;          // decoder c0 blocks composed with their transposed conv (TS2D_UPC=0 falls back to two kernels)
     unsigned long long* d_prof = nullptr;     // TS2D_DBG=256: in-kernel phase counters, 8 per op (diagnostic)
@@ -250,12 +241,7 @@ int build_program(ts2d_engine* e) {
             const size_t recs = op.stride == 1 ? (size_t)(ct / 16) * 9 : (size_t)(ct / 8) * 5;
             op.dev_wh = wo; wo = align_up(wo + recs * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);                  // 1 / scale, read by the kernel
-            if (op.stride == 1) { op.dev_wp = wo; wo = align_up(wo + recs * op.cout * 16, 64); }      // plane order (conv3x3_f16x3_p)
-            if (op.stride == 1 && ct % 16 == 0 && op.cout % 64 == 0 && op.cin % 16 == 0 && op.cin_skip % 16 == 0) {
-                op.wino_ok = true;
-                op.dev_wu = wo; wo = align_up(wo + (size_t)ct * op.cout * 16, 64);
-                op.dev_wus = wo; wo = align_up(wo + 1, 64);
-            }
+            if (op.stride == 1 && op.cout % 64 == 0) { op.dev_wp = wo; wo = align_up(wo + recs * op.cout * 16, 64); }      // plane order (conv3x3_f16x3_qp)
             if (op.stride == 2 && ct % 16 == 0 && op.cout % 64 == 0) {
                 op.s2v2_ok = true; op.bn2 = op.cout % 128 == 0 ? 128 : 64;
                 op.dev_w2 = wo; wo = align_up(wo + (size_t)ct * 9 * op.cout, 64);
@@ -391,7 +377,7 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                             const int chunk = ci / 16, cc = ci % 16, bn = co_n % 64 == 0 ? 64 : 32;
                             uint16_t* rec = d + ((((size_t)chunk * (co_n / bn) + co / bn) * 9 + tap) * bn + co % bn) * 32;
                             rec[cc] = hi; rec[16 + cc] = lo;
-                            {   // plane order of conv3x3_f16x3_p: [chunk][column tile][tap][hi,lo][h][column][8 halves]
+                            if (bn == 64) {   // plane order of conv3x3_f16x3_qp: [chunk][column tile][tap][hi,lo][h][column][8 halves]
                                 uint16_t* wp = reinterpret_cast<uint16_t*>(out + op.dev_wp);
                                 const size_t base = (((size_t)chunk * (co_n / bn) + co / bn) * 9 + tap) * 4;
                                 wp[((base + 0 + cc / 8) * bn + co % bn) * 8 + cc % 8] = hi;
@@ -500,42 +486,6 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                     bv[(size_t)(ry * 3 + rx) * co_n + co] = (float)acc;
                 }
         }
-    }
-    for (const Op& op : e->ops) {
-        if (!op.wino_ok) continue;
-        // Winograd filter transform U = G g G^T in fp64 (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), then the usual power-of-two
-        // pre-scale and fp16 hi/lo split; one contiguous 64-KB block per (chunk of 16 input channels, tile of 64 output channels).
-        const int ct = op.cin + op.cin_skip, co_n = op.cout;
-        const float* w = blob + op.blob_w;
-        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-        std::vector<double> U((size_t)co_n * ct * 16);
-        double mx = 0.0;
-        for (int co = 0; co < co_n; ++co)
-            for (int ci = 0; ci < ct; ++ci) {
-                const float* g = w + ((size_t)co * ct + ci) * 9;
-                double t[4][3];
-                for (int i = 0; i < 4; ++i)
-                    for (int b = 0; b < 3; ++b) t[i][b] = G[i][0] * g[0 * 3 + b] + G[i][1] * g[1 * 3 + b] + G[i][2] * g[2 * 3 + b];
-                for (int i = 0; i < 4; ++i)
-                    for (int j = 0; j < 4; ++j) {
-                        const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
-                        U[((size_t)co * ct + ci) * 16 + i * 4 + j] = u;
-                        mx = std::max(mx, std::fabs(u));
-                    }
-            }
-        const float wscale = (mx > 0.0 && std::isfinite(mx)) ? std::exp2(std::floor(std::log2(16383.0 / mx))) : 1.f;
-        out[op.dev_wus] = 1.0f / wscale;
-        uint16_t* d = reinterpret_cast<uint16_t*>(out + op.dev_wu);
-        for (int co = 0; co < co_n; ++co)
-            for (int ci = 0; ci < ct; ++ci)
-                for (int xi = 0; xi < 16; ++xi) {
-                    const float v = (float)(U[((size_t)co * ct + ci) * 16 + xi] * (double)wscale);
-                    const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
-                    const size_t blk = ((size_t)(ci / 16) * (co_n / 64) + co / 64) * (16 * 2 * 2 * 64 * 8);
-                    const int hh = (ci % 16) / 8, e8 = ci % 8, col = co % 64;
-                    d[blk + ((((size_t)xi * 2 + 0) * 2 + hh) * 64 + col) * 8 + e8] = hi;
-                    d[blk + ((((size_t)xi * 2 + 1) * 2 + hh) * 64 + col) * 8 + e8] = lo;
-                }
     }
     for (const Op& op : e->ops) {
         const int ct = op.cin + op.cin_skip, co_n = op.cout;
@@ -652,14 +602,6 @@ hipError_t launch_one_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t
     hipLaunchKernelGGL(kern, dim3(grid, a.ksplit), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
-template <int BN, bool PFS>
-hipError_t launch_p_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    static std::atomic<uint64_t> attr_done{0};
-    auto kern = conv3x3_f16x3_p<BN, PFS>;
-    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(kern), attr_done); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid, 1), dim3(kBlock), smem, st, a);
-    return hipGetLastError();
-}
 template <int BN, bool PFS, bool PIPE, typename ST, int NP>
 hipError_t launch_one_s2_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
     static std::atomic<uint64_t> attr_done{0};
@@ -756,7 +698,7 @@ size_t part_floats_needed(const ts2d_engine* e, int B, int H, int W) {
         if (op.type != OP_CONV) continue;
         const int Ht = H >> op.level, Wt = W >> op.level;
         TileGeom g = tile_geom(B, Ht, Wt, op.stride, 9);
-        if (g.lgNIMG == 0) mx = std::max(mx, (size_t)B * g.tiles_x * g.tiles_y * op.cout * 2);
+        if (g.lgNIMG == 0) mx = std::max(mx, (size_t)B * g.tiles_x * g.tiles_y * op.cout * 4);      // (S, Q, K, n) per (tile, channel)
     }
     return mx;
 }
@@ -839,8 +781,12 @@ int workspace_release(ts2d_engine* e, hipStream_t st) {
     return TS2D_OK;
 }
 
-int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st) {
+// clear_flags: first batch of a call.  The non-finite flag is cleared HERE, behind workspace_acquire: the previous run's head kernel
+// (possibly on another stream) sets it with atomicOr, and a memset issued before the stream is ordered behind that run could wipe
+// or pre-empt it.  ts2d_engine_predict_tiled clears it once per call, not per chunk, so an earlier chunk's inf / NaN survives.
+int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st, bool clear_flags = true) {
     TRY(workspace_acquire(e, st));
+    if (clear_flags) HIP_TRY(hipMemsetAsync(e->d_flags, 0, 2 * sizeof(int), st));
     const int rc = run_forward_impl(e, d_in, B, H, W, d_logits, d_mask, st);
     const int rc2 = workspace_release(e, st);       // also after a failed launch: earlier kernels of the run may be in flight
     return rc != TS2D_OK ? rc : rc2;
@@ -894,7 +840,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             fa.lgTH = g.lgTH; fa.lgTW = g.lgTW; fa.lgNIMG = g.lgNIMG; fa.tiles_x = g.tiles_x; fa.tiles_y = g.tiles_y;
             fa.n_mtiles = g.n_mtiles; fa.PH = g.PH; fa.PW = g.PW;
             const int kp = (op.cin + 1) / 2, nt = op.cout / 32, P = (g.PH * g.PW) << g.lgNIMG;
-            const size_t smem = std::max((size_t)P * (2 * kp + 1) * sizeof(float), (size_t)4 * op.cout * 2 * sizeof(float));
+            const size_t smem = std::max((size_t)P * (2 * kp + 1) * sizeof(float), (size_t)4 * op.cout * 4 * sizeof(float));
             TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_first");
             // complete one-image 256-pixel tiles everywhere: persistent workgroups (4 per CU) with the next tile's patch in flight
             const bool first_full = g.lgNIMG == 0 && g.lgTH + g.lgTW == 8 && g.lgTW >= 4 && H % (1 << g.lgTH) == 0 && W % (1 << g.lgTW) == 0 &&
@@ -1011,29 +957,6 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const int P = (g.PH * g.PW) << g.lgNIMG;
             const bool split = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT;
             if (f16 && !split) return fail(TS2D_ERR_INVALID, "op %s has no fp16 kernel (channel counts must be multiples of 16)", op.name.c_str());
-            if (conv && split && !f16 && op.wino_ok && e->wino_min > 0 && ct_total(op) >= e->wino_min && e->use_one && stride == 1 && g.lgNIMG == 0 &&
-                Ht % 8 == 0 && Wt % 32 == 0 && ca.lg_tx >= 0 && ca.lg_tpi >= 0 && lg_exact(op.cout / 64) >= 0 &&
-                (size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4 < ((size_t)1 << 31) && (size_t)Ht * Wt * op.cout * 4 < ((size_t)1 << 31)) {
-                // stride-1 block on full 8 x 32 tiles: Winograd F(2x2,3x3), one 512-thread workgroup per CU, 64 output columns
-                ca.n_ctiles = op.cout / 64; ca.lg_nct = lg_exact(ca.n_ctiles);
-                ca.wph = wts + op.dev_wu; ca.oscale = wts + op.dev_wus; ca.part = e->d_part;
-                // (grid: 8 XCD lanes x enough rows for either block map of the kernel; surplus blocks return at once)
-                const int gridw = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
-                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_wino");
-                {
-                    static std::atomic<uint64_t> donew{0};
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_wino), donew));
-                    hipLaunchKernelGGL(conv3x3_wino, dim3(gridw), dim3(kWThreads), kWLds, st, ca);
-                }
-                HIP_TRY(hipGetLastError());
-                TRY(prof_end(e, st));
-                TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
-                launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
-                                   op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
-                HIP_TRY(hipGetLastError());
-                TRY(prof_end(e, st));
-                continue;
-            }
             if (conv && split && op.s2v2_ok && e->use_s2v2 && e->use_one && stride == 2 && g.lgNIMG == 0 && Ht % 8 == 0 && Wt % 32 == 0 &&
                 ca.lg_tx >= 0 && ca.lg_tpi >= 0 && lg_exact(op.cout / op.bn2) >= 0 &&
                 (size_t)Hin * Win * op.cin * 4 < ((size_t)1 << 31) && (size_t)Ht * Wt * op.cout * 4 < ((size_t)1 << 31)) {
@@ -1077,7 +1000,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 if (f16) {
                     static std::atomic<uint64_t> done16{0};
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_res32<_Float16, 1>), done16));
-                    hipLaunchKernelGGL((conv3x3_res32<_Float16, 1>), dim3(nbk), dim3(kBlock), 9 * 4 * 512 + 4 * kResPS + 1024, st, ra);
+                    hipLaunchKernelGGL((conv3x3_res32<_Float16, 1>), dim3(nbk), dim3(kBlock), 9 * 4 * 512 + 4 * kResPS + 1536, st, ra);
                 } else {
                     static std::atomic<uint64_t> done32{0};
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_res32<float, 3>), done32));
@@ -1112,10 +1035,10 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 continue;
             }
             size_t smem = std::max((size_t)(((P * (op.ck + 4) + 3) & ~3) + taps * (op.ck / 8) * bn * 8) * sizeof(float),
-                                   (size_t)4 * bn * 2 * sizeof(float));
+                                   (size_t)4 * bn * 4 * sizeof(float));
             if (split) {
                 smem = stride == 1 ? (size_t)P * kRec + (size_t)9 * bn * kRec : (size_t)P * kRec8 + (size_t)5 * bn * kRec;
-                smem = std::max(smem, (size_t)4 * bn * 2 * sizeof(float));
+                smem = std::max(smem, (size_t)4 * bn * 4 * sizeof(float));
                 ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
             }
             const int ksplit = split ? choose_ksplit(e, op, B, H, W) : 1;
@@ -1134,7 +1057,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
             const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32;
             const bool one_s2 = split && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;
-            const bool qtile = one && e->use_q && bn == 64 && ct_total(op) >= (e->use_qp ? 64 : 128) && Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr &&      // (the per-tile kernel pays off from 8 chunks on, the persistent one from 4: measured)
+            const bool qtile = one && e->use_q && bn == 64 && ct_total(op) >= 64 && Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr &&      // (pays off from 4 chunks on: measured)
                                (op.skip < 0 || e->tensors[op.skip].scale != nullptr) && lg_exact(Wt / 32) >= 0 && lg_exact((Wt / 32) * (Ht / 16)) >= 0;
             if (qtile) {
                 // complete 16 x 32 tiles x 64 columns, normalised sources: one 512-thread workgroup per CU, patch and weights
@@ -1143,29 +1066,11 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 ca.tiles_x = Wt / 32; ca.tiles_y = Ht / 16; ca.n_mtiles = B * ca.tiles_x * ca.tiles_y;
                 ca.lg_tx = lg_exact(ca.tiles_x); ca.lg_tpi = lg_exact(ca.tiles_x * ca.tiles_y);
                 const int gridq = (ca.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
-                const int gridp = 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles));       // one persistent workgroup per CU
-                if (e->use_qp && e->dbg == 0 && gridp < gridq) {
-                    static std::atomic<uint64_t> doneqp{0};
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp), doneqp));
-                    hipLaunchKernelGGL(conv3x3_f16x3_qp, dim3(gridp), dim3(kQThreads), kQpLds, st, ca);
-                    le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp");
-                } else {
-#define TS2D_Q_LAUNCH(D_) do { static std::atomic<uint64_t> doneq_{0}; \
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_q<D_>), doneq_)); \
-                    hipLaunchKernelGGL(conv3x3_f16x3_q<D_>, dim3(gridq), dim3(kQThreads), kQLds, st, ca); } while (0)
-                switch (e->dbg) {       // (TS2D_DBG: the diagnostic variants behind the numbers in kernels_f16x3_q.h)
-                    case 4: TS2D_Q_LAUNCH(4); break; case 64: TS2D_Q_LAUNCH(64); break; case 128: TS2D_Q_LAUNCH(128); break;
-                    default: TS2D_Q_LAUNCH(0); break;
-                }
-#undef TS2D_Q_LAUNCH
-                le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_q");
-                }
-            } else if (one && e->use_p && bn == 64 && Ht % 8 == 0 && Wt % 32 == 0 && g.lgTH == 3 && g.lgTW == 5) {
-                // complete 8 x 32 tiles x 64 columns: plane layout (conflict-free LDS; same speed as the record layout - measured;
-                // the 32-column variant lost its third workgroup per CU to registers and stays on conv3x3_f16x3_one)
-                ca.wph = wts + op.dev_wp;
-                const size_t smem_p = (size_t)4 * kPPlane + (size_t)9 * 4 * bn * 16;
-                le = launch_p_inst<64, true>(ca, grid, smem_p, st); prof_kernel(e, "conv3x3_f16x3_p<64>");
+                const int gridp = std::min(gridq, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));     // one persistent workgroup per CU
+                static std::atomic<uint64_t> doneqp{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp), doneqp));
+                hipLaunchKernelGGL(conv3x3_f16x3_qp, dim3(gridp), dim3(kQThreads), kQpLds, st, ca);
+                le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp");
             } else if (one) {     // tile inside one image: lean staging path
                 le = launch_one(bn, ca, grid, smem, st); prof_kernel(e, bn == 64 ? "conv3x3_f16x3_one<64>" : "conv3x3_f16x3_one<32>");
             } else if (one_s2) {
@@ -1261,13 +1166,10 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_ONE")) e->use_one = getenv("TS2D_ONE")[0] == '1';
         if (getenv("TS2D_RES")) e->use_res = getenv("TS2D_RES")[0] == '1';
         if (getenv("TS2D_S2V2")) e->use_s2v2 = getenv("TS2D_S2V2")[0] == '1';
-        if (getenv("TS2D_P")) e->use_p = getenv("TS2D_P")[0] == '1';
-        if (getenv("TS2D_QP")) e->use_qp = getenv("TS2D_QP")[0] == '1';
         if (getenv("TS2D_Q")) e->use_q = getenv("TS2D_Q")[0] == '1';
         if (getenv("TS2D_UPQ")) e->use_upq = getenv("TS2D_UPQ")[0] == '1';
         if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
-        if (getenv("TS2D_WINO")) e->wino_min = atoi(getenv("TS2D_WINO"));
     }
     int rc = build_program(e);
     if (rc != TS2D_OK) { delete e; return rc; }
@@ -1348,7 +1250,6 @@ int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W,
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
     const int K = e->arch.num_classes;
-    HIP_TRY(hipMemsetAsync(e->d_flags, 0, 2 * sizeof(int), st));
     if (on_device) return run_forward(e, input, B, H, W, logits, mask_packed, st);
     // host buffers: staged through the workspace, synchronous
     HIP_TRY(hipMemcpyAsync(e->d_in_stage, input, (size_t)B * e->arch.input_channels * H * W * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1401,7 +1302,6 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
     HIP_TRY(hipMemcpyAsync(d_tx, tile_x, (size_t)n_tiles * 4, hipMemcpyHostToDevice, st));
     int* d_flag = reinterpret_cast<int*>(b + o_flag);
     HIP_TRY(hipMemsetAsync(d_flag, 0, 4, st));
-    HIP_TRY(hipMemsetAsync(e->d_flags, 0, 2 * sizeof(int), st));
     HIP_TRY(hipMemcpyAsync(d_vf, vflip, 16, hipMemcpyHostToDevice, st));
     if (gaussian_f16) HIP_TRY(hipMemcpyAsync(d_g, gaussian_f16, (size_t)ph * pw * 2, hipMemcpyHostToDevice, st));
     {
@@ -1411,7 +1311,7 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
     }
     for (int r0 = 0; r0 < rows; r0 += chunk) {
         const int nb = std::min(chunk, rows - r0);
-        TRY(run_forward(e, d_batch + (size_t)r0 * C * ph * pw, nb, ph, pw, d_log + (size_t)r0 * K * ph * pw, nullptr, st));
+        TRY(run_forward(e, d_batch + (size_t)r0 * C * ph * pw, nb, ph, pw, d_log + (size_t)r0 * K * ph * pw, nullptr, st, r0 == 0));
     }
     {
         const long long total = (long long)K * Hp * Wp;
@@ -1447,7 +1347,9 @@ int ts2d_engine_check(ts2d_engine* e) {
         return f;
     };
     const int B = e->lastB, H = e->lastH, W = e->lastW;
-    std::string where = "head";
+    // (only the LAST batch of the call is still resident: after a multi-chunk ts2d_engine_predict_tiled an earlier chunk's inf / NaN
+    //  is reported, but located only if the last chunk shows it too)
+    std::string where = "the head (or an earlier batch of the same call: the diagnosis sees the last batch only)";
     if (e->last_input && has_nonfinite(e->last_input, (size_t)B * e->arch.input_channels * H * W, false) == 1) where = "the network input";
     else
         for (const Op& op : e->ops) {
@@ -1646,6 +1548,7 @@ int ts2d_engine_destroy(ts2d_engine* e) {
     for (Launch& l : e->launches) { if (l.e0) (void)hipEventDestroy(l.e0); if (l.e1) (void)hipEventDestroy(l.e1); }
     if (e->d_ws) (void)hipFree(e->d_ws);
     if (e->d_flags) (void)hipFree(e->d_flags);
+    if (e->d_prof) (void)hipFree(e->d_prof);
     if (e->d_sw) (void)hipFree(e->d_sw);
     if (e->d_weights) (void)hipFree(e->d_weights);
     if (e->stream) (void)hipStreamDestroy(e->stream);

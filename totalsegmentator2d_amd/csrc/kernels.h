@@ -31,6 +31,35 @@ constexpr f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.
         atomicAdd(p_ + 7, 1ull); }
 
 
+// ------------------------------------------------------------------------------------------------------------
+// InstanceNorm partial statistics as SHIFTED sums (round 3; SURVEY section 7 "InstanceNorm numerics").
+// A tile's partial for one channel is the float4 (S, Q, K, n):  S = sum(v - K), Q = sum((v - K)^2) over the n values v of the
+// tile AS STORED (after the bias, after rounding to the storage type), K = a pivot taken from the tile itself (the value of one of
+// its pixels).  Plain sum(v), sum(v^2) in fp32 lose (mean / sigma)^2 of their digits when var = E[v^2] - E[v]^2 is formed - a conv bias of
+// 100 sigma, or a network input with an offset, costs 1e-3 on the normalised activations; torch computes the mean first and then
+// sum((x - mean)^2).  With the pivot the fp32 sums run over deviations of the size of sigma whatever the mean is, and everything that
+// involves K itself happens in double in finalize_stats_t.  Cost: one v_sub_f32 per output element in the epilogue, 16 instead of 8
+// bytes per (tile, channel).  Deterministic: fixed summation order, no atomics, the pivot depends on the slice's own data only.
+// Wave-level protocol (32x32 MFMA layouts: channel = lane & 31, both lane halves hold pixels of that channel):
+//   kv = stat_pivot(first stored value of lane half 0);  per element: d = v - kv; s += d; q = fma(d, d, q);
+//   stat_wave_put(red, w * BN + column, s, q, kv, n)  [h == 0 lanes, after adding the other half];  barrier;
+//   stat_tile_store(red, waves, BN, column, part entry)  [BN threads]: waves rebased onto wave 0's pivot, all terms of size sigma.
+__device__ __forceinline__ float stat_pivot(float v_first) { return __shfl(v_first, (int)(threadIdx.x & 31)); }   // lane r of half 0 -> both halves
+__device__ __forceinline__ void stat_wave_put(float* red, int slot, float s, float q, float kv, float n) {
+    *reinterpret_cast<f32x4*>(red + 4 * slot) = f32x4{s, q, kv, n};
+}
+__device__ __forceinline__ void stat_tile_store(const float* red, int nwaves, int bn, int col, float* part_entry) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(red + 4 * col);
+    for (int ww = 1; ww < nwaves; ++ww) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(red + 4 * (ww * bn + col));
+        const float d = b[2] - a[2];                                   // pivot of wave ww relative to wave 0's: a difference of two samples
+        a[1] += b[1] + d * (2.f * b[0] + b[3] * d);                      // sum((v - K0)^2) = sum((v - Kw)^2) + 2 d sum(v - Kw) + n d^2
+        a[0] += b[0] + b[3] * d;
+        a[3] += b[3];
+    }
+    *reinterpret_cast<f32x4*>(part_entry) = a;
+}
+
 constexpr int kBlock = 256;   // threads per workgroup (4 waves, one per SIMD)
 constexpr int kBM = 256;      // output pixels per workgroup tile
 
@@ -242,15 +271,17 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
     }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).
-    float st_s[NT], st_q[NT];
+    float st_s[NT], st_q[NT], st_k[NT], st_n[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { st_s[nt] = 0.f; st_q[nt] = 0.f; }
+    for (int nt = 0; nt < NT; ++nt) { st_s[nt] = 0.f; st_q[nt] = 0.f; st_n[nt] = 0.f; }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = n0col + nt * 32 + r;
         int co = col, oa = 0, ob = 0;
         if (EPI == 1) { const int ab = (n0col + nt * 32) / a.Cout; co = col - ab * a.Cout; oa = ab >> 1; ob = ab & 1; }
         const float bv = a.bias[co];
+        const float kv = stat_pivot(acc_t[0][nt][0] + bv);      // (a pixel outside the image is still a finite value: fine as a pivot)
+        st_k[nt] = kv;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -263,7 +294,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
                     const float v = acc_t[mt][nt][i] + bv;
                     if (EPI == 0) {
                         a.dst[((size_t)(n * a.Ht + oy) * a.Wt + ox) * a.Cout + co] = v;
-                        st_s[nt] += v; st_q[nt] += v * v;
+                        const float d = v - kv;
+                        st_s[nt] += d; st_q[nt] = __builtin_fmaf(d, d, st_q[nt]); st_n[nt] += 1.f;
                     } else {
                         a.dst[((size_t)(n * 2 * a.Ht + 2 * oy + oa) * (2 * a.Wt) + 2 * ox + ob) * a.Cout + co] = v;
                     }
@@ -273,21 +305,15 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
     }
     if (EPI == 0 && a.part != nullptr) {   // fused InstanceNorm partial statistics (host guarantees NIMG == 1)
         lds_barrier();
-        float* red = smem;                 // [4 waves][BN][2]
+        float* red = smem;                 // [4 waves][BN][4]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float s = st_s[nt], q = st_q[nt];
-            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-            if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
+            float s = st_s[nt], q = st_q[nt], n = st_n[nt];
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32); n += __shfl_xor(n, 32);
+            if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], n);
         }
         lds_barrier();
-        if (tid < BN) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
-            float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
-            p[0] = s; p[1] = q;
-        }
+        if (tid < BN) stat_tile_store(red, 4, BN, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 4);
     }
 }
 
@@ -295,7 +321,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
 // InstanceNorm statistics -> per-(n,c) scale/shift.  scale = gamma * rstd, shift = beta - mean * scale,
 // biased variance, eps inside the sqrt, combined in double.
 // ------------------------------------------------------------------------------------------------------------
-// (a) from the conv epilogue's per-tile partial (sum, sum of squares).  Grid (B, C/32), 32 TL threads = TL tile lanes x 32
+// (a) from the conv epilogue's per-tile shifted partials (S, Q, K, n) - see "InstanceNorm partial statistics" above.  Grid (B, C/32), 32 TL threads = TL tile lanes x 32
 // channels (TL = 32 for the levels with hundreds of tiles per image: a 64-block grid is latency-bound, so each block brings 1024
 // threads; TL = 8 otherwise); fixed summation order -> bit-reproducible, and independent of the batch a slice travels in.
 template <int TL>
@@ -304,9 +330,13 @@ __global__ __launch_bounds__(32 * TL) void finalize_stats_t(const float* __restr
                                                            float eps, float* __restrict__ scale, float* __restrict__ shift) {
     const int n = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, tl = threadIdx.x >> 5;
     __shared__ double rs[TL][32], rq[TL][32];
-    const float2* p = reinterpret_cast<const float2*>(part) + (size_t)n * ntiles * C + c;
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + (size_t)n * ntiles * C + c;
     double s = 0.0, q = 0.0;
-    for (int t = tl; t < ntiles; t += TL) { const float2 v = p[(size_t)t * C]; s += (double)v.x; q += (double)v.y; }
+    for (int t = tl; t < ntiles; t += TL) {          // (S, Q, K, n) -> sum(v), sum(v^2): everything that involves the pivot, in double
+        const f32x4 v = p[(size_t)t * C];
+        const double k = (double)v[2], nn = (double)v[3];
+        s += (double)v[0] + nn * k; q += (double)v[1] + k * (2.0 * (double)v[0] + nn * k);
+    }
     rs[tl][cl] = s; rq[tl][cl] = q;
     __syncthreads();
     if (tl == 0) {

@@ -80,13 +80,15 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const int TH = 1 << a.lgTH, TW = 1 << a.lgTW, NIMG = 1 << a.lgNIMG;
     const float oscale = *a.oscale;
-    float st_s[NT], st_q[NT];
+    float st_s[NT], st_q[NT], st_k[NT], st_n[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { st_s[nt] = 0.f; st_q[nt] = 0.f; }
+    for (int nt = 0; nt < NT; ++nt) { st_s[nt] = 0.f; st_q[nt] = 0.f; st_n[nt] = 0.f; }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
         const float bv = a.ksplit > 1 ? 0.f : a.bias[co];      // split-K partials: bias is added by splitk_reduce_stats
+        const float kv = stat_pivot(round_act<ST>(__builtin_fmaf(acc_t[0][nt][0], oscale, bv)));      // shifted statistics (kernels.h)
+        st_k[nt] = kv;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -100,7 +102,8 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
                     const size_t o = ((size_t)(n * a.Ht + oy) * a.Wt + ox) * a.Cout + co;
                     if (a.ksplit > 1) a.dst[(size_t)blockIdx.y * a.kslice_stride + o] = v;          // fp32 partial
                     else { store_act<ST>(a.dst, o, v); v = round_act<ST>(v); }                      // statistics of what is stored
-                    st_s[nt] += v; st_q[nt] = __builtin_fmaf(v, v, st_q[nt]);
+                    const float d = v - kv;
+                    st_s[nt] += d; st_q[nt] = __builtin_fmaf(d, d, st_q[nt]); st_n[nt] += 1.f;
                 }
             }
         }
@@ -110,18 +113,12 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
         float* red = reinterpret_cast<float*>(smem8);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float s = st_s[nt], q = st_q[nt];
-            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-            if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
+            float s = st_s[nt], q = st_q[nt], n = st_n[nt];
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32); n += __shfl_xor(n, 32);
+            if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], n);
         }
         lds_barrier();
-        if (tid < BN) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
-            float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
-            p[0] = s; p[1] = q;
-        }
+        if (tid < BN) stat_tile_store(red, 4, BN, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 4);
     }
 }
 
@@ -150,7 +147,7 @@ __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&a
     const float oscale = *a.oscale;
     const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * sizeof(ST)), 0x00020000);
-    float st_s[NT], st_q[NT];
+    float st_s[NT], st_q[NT], st_k[NT];
     float bvs[NT];       // every bias value before the first store: a load issued between stores waits (in-order vmcnt) for the stores ahead of it
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bvs[nt] = a.bias[n0col + nt * 32 + r];
@@ -158,6 +155,7 @@ __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&a
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
         const float bv = bvs[nt];
+        const float kv = stat_pivot(round_act<ST>(__builtin_fmaf(acc_t[0][nt][0], oscale, bv)));      // shifted statistics (kernels.h)
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -170,11 +168,11 @@ __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&a
                 const unsigned soff = (unsigned)((((rowoff & (TW - 1)) + (rowoff >> a.lgTW) * a.Wt) * a.Cout) * (int)sizeof(ST));   // scalar
                 float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);          // explicit FMAs: the same rounding as split_epilogue
                 buffer_store_act<ST>(v, rs, voff, soff);
-                v = round_act<ST>(v);                                                // statistics of what is stored
-                s += v; q = __builtin_fmaf(v, v, q);
+                const float d = round_act<ST>(v) - kv;                               // statistics of what is stored
+                s += d; q = __builtin_fmaf(d, d, q);
             }
         }
-        st_s[nt] = s; st_q[nt] = q;
+        st_s[nt] = s; st_q[nt] = q; st_k[nt] = kv;
     }
     if (a.part != nullptr) {
         lds_barrier();
@@ -183,16 +181,10 @@ __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&a
         for (int nt = 0; nt < NT; ++nt) {
             float s = st_s[nt], q = st_q[nt];
             s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-            if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
+            if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], 64.f);
         }
         lds_barrier();
-        if (tid < BN) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
-            float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
-            p[0] = s; p[1] = q;
-        }
+        if (tid < BN) stat_tile_store(red, 4, BN, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 4);
     }
 }
 

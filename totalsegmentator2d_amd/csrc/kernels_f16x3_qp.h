@@ -1,22 +1,33 @@
-// conv3x3_f16x3_qp: conv3x3_f16x3_q with PERSISTENT workgroups - the pipeline of kernels_f16x3_q.h (patch and weights double-buffered,
-// weights by LDS-DMA, one barrier per chunk) runs over ONE stream of (tile, chunk) items per workgroup instead of being filled and
-// drained for every tile: no synchronous first chunk, no surplus prefetches at the end of a tile, the epilogue of a tile overlaps
-// the staging of the next tile's first chunks.  Same tap order, chunking and per-chunk accumulators: conv outputs bit-identical
-// to conv3x3_f16x3_q / _p / _one.
+// conv3x3_f16x3_qp: the stride-1 3x3 split kernel as ONE persistent 512-thread workgroup per CU with everything double-buffered.
+//
+// LDS layout ("k-group major planes", round 2): patch plane[part hi,lo][h][pixel] and weights plane[tap][part][h][column] of 16-byte
+// slots (8 channels): the 32 lanes of a lane half read 32 CONSECUTIVE slots for a 32x32x16 fragment (conflict-free ds_read_b128 at
+// any alignment), 8 consecutive lanes of the staging phase write 8 consecutive slots, every fragment address is lane base +
+// immediate, and the weight block of a (chunk, column tile) is stored in HBM in LDS order so that it travels L2 -> LDS by
+// global_load_lds (no registers, no ds_write).  Tile = 16 x 32 pixels x 64 channels, 8 waves (wave w = rows 2w, 2w + 1).
+// Pipeline: ONE stream of (tile, chunk) items per workgroup - MFMAs of item i, conversion + weight DMA of item i+1, raw loads of
+// item i+2 - one raw s_barrier per item; a tile's epilogue overlaps the staging of the next tile's first chunks.  Same tap order,
+// chunking and per-chunk accumulators as conv3x3_f16x3_one: conv outputs bit-identical to it.
+// (Round-2 predecessors, removed in round 3 - numbers in DESIGN.md section 4: conv3x3_f16x3_p = the plane layout on 8 x 32 tiles with
+//  256-thread workgroups, same speed as the 80-byte record layout; conv3x3_f16x3_q = this pipeline filled and drained per tile:
+//  512 -> 512 block 0.80 -> 0.73 ms, but slower than _p below 8 chunks per tile.)
 //
 // A workgroup (grid = 8 * n_ctiles * m workgroups, one per CU) keeps its XCD lane and its column tile and walks the pixel tiles
 // v = blockIdx.x + k * gridDim.x of the XCD-aware map of the other kernels.  Three pipeline stages per iteration: MFMAs of item i,
 // conversion + weight DMA of item i+1, raw patch / scale / shift loads of item i+2; each stage carries its own (tile, chunk)
 // counter; the in-image test of a staging unit is recomputed from the tile origin (two compares per unit) instead of being held
-// in registers per tile.  LDS: the q kernel's 152064 bytes + 4096 for the statistics exchange (the patch buffers stay busy).
+// in registers per tile.  LDS: 152064 bytes + 8192 for the statistics exchange (the patch buffers stay busy).
 // Measured (gpurun r2 qp1/qp2): 64 -> 64 at level 1 0.93 (conv3x3_f16x3_p) -> 0.84-0.89 ms, 128 -> 128 0.83 -> 0.78, 256 / 512 channels
 // unchanged (0.76 / 0.74): the gain is the per-tile fill and drain, which weighs less the more chunks a tile has.
 #pragma once
-#include "kernels_f16x3_q.h"
+#include "kernels_f16x3_one.h"
 
 namespace ts2d {
 
-constexpr int kQpRed = kQLds, kQpLds = kQLds + 4096;
+constexpr int kPPW = 34;                                     // patch row: 32 pixels + halo, one 16-byte slot per pixel and plane
+constexpr int kQThreads = 512, kQRows = 18, kQSlots = kQRows * kPPW, kQPlane = kQSlots * 16, kQPatch = 4 * kQPlane;
+constexpr int kQWts = 9 * 4 * 64 * 16, kQLds = 2 * kQPatch + 2 * kQWts;      // 2 x 39168 (patch) + 2 x 36864 (weights) = 152064 bytes
+constexpr int kQpRed = kQLds, kQpLds = kQLds + 8192;          // + the statistics exchange [8 waves][64 columns] x (S, Q, K, n)
 
 __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs a) {
     constexpr int BN = 64, NT = 2, MAXU = 3, WTAP = 4 * BN * 16;
@@ -42,7 +53,7 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
     const float* const sc1p = a.src1 ? a.sc1 : a.sc0;
     const float* const sh1p = a.src1 ? a.sh1 : a.sh0;
 
-    // ---- staging units (as conv3x3_f16x3_q): patch pixel pp = 32 (8 it + w) + (lane & 7) + 8 (lane >> 4) -> (py, px), tile-independent
+    // ---- staging units: patch pixel pp = 32 (8 it + w) + (lane & 7) + 8 (lane >> 4) -> (py, px), tile-independent
     int upk[MAXU], lw[MAXU];
 #pragma unroll
     for (int it = 0; it < MAXU; ++it) {
@@ -171,7 +182,8 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
                 acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur_][mt][0], fb[cur_][nt][0], acc_c[mt][nt], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0); }
         TS2D_LOAD_FRAGS(0, 0)
-        // (memory operations of an item: every use of a loaded register first, THEN the weight DMA - kernels_f16x3_q.h)
+        // (memory operations of an item: every use of a loaded register first, THEN the weight DMA: hipcc answers ANY use of a loaded
+        //  register with s_waitcnt vmcnt(0) while a global_load_lds is in flight, and falls back to vmcnt(0) at control-flow joins)
         TS2D_TAP(0, convert(0, pb_next);)
         TS2D_TAP(1, convert(1, pb_next);)
         TS2D_TAP(2, convert(2, pb_next); prefetch(nx2);)
@@ -189,13 +201,14 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
             tile_origin(cur.k, nimg, ty0, tx0, tin);
             const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
             const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(a.dst) + (size_t)nimg * img_el, 0, (int)(img_el * 4), 0x00020000);
-            float st_s[NT], st_q[NT], bvs[NT];
+            float st_s[NT], st_q[NT], st_k[NT], bvs[NT];
             const float oscale = *a.oscale;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bvs[nt] = a.bias[n0col + nt * 32 + r];       // (both before the first store)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = n0col + nt * 32 + r;
+                const float kv = stat_pivot(__builtin_fmaf(acc_t[0][nt][0], oscale, bvs[nt]));      // shifted statistics (kernels.h)
                 float s = 0.f, q = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
@@ -207,27 +220,22 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
                         const unsigned soff = (unsigned)(rowoff * a.Cout * 4);
                         const float v = __builtin_fmaf(acc_t[mt][nt][e], oscale, bvs[nt]);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
-                        s += v; q = __builtin_fmaf(v, v, q);
+                        const float d = v - kv;
+                        s += d; q = __builtin_fmaf(d, d, q);
                         acc_t[mt][nt][e] = 0.f;
                     }
                 }
-                st_s[nt] = s; st_q[nt] = q;
+                st_s[nt] = s; st_q[nt] = q; st_k[nt] = kv;
             }
             float* red = reinterpret_cast<float*>(smem8 + kQpRed);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 float s = st_s[nt], q = st_q[nt];
                 s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-                if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
+                if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], 64.f);
             }
             lds_barrier();
-            if (tid < BN) {
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int ww = 0; ww < 8; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
-                float* p = a.part + ((size_t)(nimg * tpi + tin) * a.Cout + n0col + tid) * 2;
-                p[0] = s; p[1] = q;
-            }
+            if (tid < BN) stat_tile_store(red, 8, BN, tid, a.part + ((size_t)(nimg * tpi + tin) * a.Cout + n0col + tid) * 4);
             // (the next use of `red` is a whole tile away: the per-item barriers below order it)
         }
         advance(cur); advance(nx1); advance(nx2);

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 1) void conv3x3_
         }
     }
 
-    float st_s[NT], st_q[NT];
+    float st_s[NT], st_q[NT], st_k[NT], st_n[NT];
     // complete one-image tile: one lane offset per 32x32 block + wave-uniform row offsets (see split_epilogue_one)
     const bool full = FULL || (a.lgNIMG == 0 && a.lgTH + a.lgTW == 8 && ty0 + TH <= a.H && tx0 + TW <= a.W && a.lgTW >= 4 && nimg0 < a.B);
     const size_t img_el = (size_t)a.H * a.W * a.Cout;
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 1) void conv3x3_
     for (int nt = 0; nt < NT; ++nt) {
         const int co = nt * 32 + r;
         const float bv = bvs[nt];
-        float ss = 0.f, qq = 0.f;
+        const float kv = stat_pivot(round_act<ST>(acc[0][nt][0] + bv));      // shifted statistics (kernels.h)
+        float ss = 0.f, qq = 0.f, nn = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             if (FULL || full) {
@@ -160,9 +161,10 @@ __global__ __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 1) void conv3x3_
                     const unsigned soff = (unsigned)((((rowoff & (TW - 1)) + (rowoff >> a.lgTW) * a.W) * a.Cout) * (int)sizeof(ST));
                     float v = acc[mt][nt][i] + bv;
                     buffer_store_act<ST>(v, rsd, voff, soff);
-                    v = round_act<ST>(v);
-                    ss += v; qq = __builtin_fmaf(v, v, qq);
+                    const float d = round_act<ST>(v) - kv;
+                    ss += d; qq = __builtin_fmaf(d, d, qq);
                 }
+                nn += 16.f;
             } else if constexpr (!FULL) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -173,31 +175,25 @@ __global__ __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 1) void conv3x3_
                     if (il < NIMG && n < a.B && oy < a.H && ox < a.W) {
                         float v = acc[mt][nt][i] + bv;
                         store_act<ST>(a.dst, ((size_t)(n * a.H + oy) * a.W + ox) * a.Cout + co, v);
-                        v = round_act<ST>(v);
-                        ss += v; qq = __builtin_fmaf(v, v, qq);
+                        const float d = round_act<ST>(v) - kv;
+                        ss += d; qq = __builtin_fmaf(d, d, qq); nn += 1.f;
                     }
                 }
             }
         }
-        st_s[nt] = ss; st_q[nt] = qq;
+        st_s[nt] = ss; st_q[nt] = qq; st_k[nt] = kv; st_n[nt] = nn;
     }
     if (a.part != nullptr) {
         lds_barrier();
         float* red = smem;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float s = st_s[nt], q = st_q[nt];
-            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-            if (h == 0) { red[(w * NT * 32 + nt * 32 + r) * 2] = s; red[(w * NT * 32 + nt * 32 + r) * 2 + 1] = q; }
+            float s = st_s[nt], q = st_q[nt], n = st_n[nt];
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32); n += __shfl_xor(n, 32);
+            if (h == 0) stat_wave_put(red, w * NT * 32 + nt * 32 + r, s, q, st_k[nt], n);
         }
         lds_barrier();
-        if (tid < NT * 32) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) { s += red[(ww * NT * 32 + tid) * 2]; q += red[(ww * NT * 32 + tid) * 2 + 1]; }
-            float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + tid) * 2;
-            p[0] = s; p[1] = q;
-        }
+        if (tid < NT * 32) stat_tile_store(red, 4, NT * 32, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + tid) * 4);
     }
     }   // tiles of this workgroup
 }

@@ -27,7 +27,7 @@ struct Res32Args {
     const float* bias;     // [32]
     const float* oscale;   // 1 / (power-of-two weight pre-scale)
     void* dst;             // raw NHWC [B,H,W,32] output (ST)
-    float* part;           // InstanceNorm partials [n][tile (column-major index inside the image)][32][2]
+    float* part;           // InstanceNorm partials [n][tile (column-major index inside the image)][32] x (S, Q, K, n) - kernels.h
     int B, H, W;           // H % 8 == 0, W % 32 == 0
     int tiles_x, tiles_y;  // W / 32, H / 8
     int n_tiles;           // B * tiles_x * tiles_y
@@ -71,11 +71,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
         }
     }
     unsigned char* sP = smem8 + WB;                        // patch planes [part][g][pixel] x 16 B
-    // cross-wave statistics scratch: 64-byte pieces in the 12 unused slots at the end of each patch plane (split mode: the
-    // two workgroups of a CU use all 160 KiB), or behind the planes (f16 mode)
+    // cross-wave statistics scratch: 96-byte pieces (sums, squares, pivots of 8 channels) in the 12 unused slots at the end of
+    // each patch plane (split mode: the two workgroups of a CU use all 160 KiB), or behind the planes (f16 mode)
     auto scratch = [&](int ww, int gg) -> float* {
-        if (NPP == 2) return reinterpret_cast<float*>(sP + (2 * ww + (gg >> 1)) * kResPS + kResP * 16 + (gg & 1) * 64);
-        return reinterpret_cast<float*>(sP + NPP * 4 * kResPS + (ww * 4 + gg) * 64);
+        if (NPP == 2) return reinterpret_cast<float*>(sP + (2 * ww + (gg >> 1)) * kResPS + kResP * 16 + (gg & 1) * 96);
+        return reinterpret_cast<float*>(sP + NPP * 4 * kResPS + (ww * 4 + gg) * 96);
     };
 
     // ---- staging plan.  Unit (it): pixel p = 64 it + 16 w + (lane & 7) + 8 (lane >> 5), channel group sg = (lane >> 3) & 3:
@@ -210,11 +210,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
         // ---- epilogue: lane = pixel j of block pb, channels 16 cb + 4 g .. + 3: one 16-byte (fp16: 8-byte) store per block
         f32x4 ov[2][4];
         {
-            float ss[2][4], qq[2][4];                      // (sum, sum of squares) of this lane's 4 pixels per channel
-#pragma unroll
+            float ss[2][4], qq[2][4], kv[2][4];            // shifted (sum, sum of squares) of this lane's 4 pixels per channel + their pivot:
+#pragma unroll                                            // the stored value of pixel 0 of the wave's first 16-pixel block (kernels.h)
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { ss[cb][i] = 0.f; qq[cb][i] = 0.f; }
+                for (int i = 0; i < 4; ++i) {
+                    ss[cb][i] = 0.f; qq[cb][i] = 0.f;
+                    float v0 = __builtin_fmaf(acc[cb][0][i], oscale, bv[cb][i]);
+                    if constexpr (sizeof(ST) != 4) v0 = (float)(_Float16)v0;
+                    kv[cb][i] = __shfl(v0, lane & 48);
+                }
             const unsigned tile_off = (unsigned)((((tyi * 8 + 2 * w) * a.W + txi * 32) * 32) * (int)sizeof(ST));      // scalar
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb)
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
                     }
                     ov[cb][pb] = v;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { ss[cb][i] += v[i]; qq[cb][i] = __builtin_fmaf(v[i], v[i], qq[cb][i]); }
+                    for (int i = 0; i < 4; ++i) { const float d = v[i] - kv[cb][i]; ss[cb][i] += d; qq[cb][i] = __builtin_fmaf(d, d, qq[cb][i]); }
                 }
             // sum over the 16 pixels of the lane row (DPP row rotations: every lane of the row ends up with the total)
             float* sc4 = scratch(w, g);
@@ -256,18 +261,26 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
                     ss[cb][i] = s; qq[cb][i] = q;
                 }
                 if (j == 0) {                              // 4 lanes per wave (g = 0..3): channels 16 cb + 4 g + i
-                    *reinterpret_cast<f32x4*>(sc4 + cb * 8) = f32x4{ss[cb][0], ss[cb][1], ss[cb][2], ss[cb][3]};
-                    *reinterpret_cast<f32x4*>(sc4 + cb * 8 + 4) = f32x4{qq[cb][0], qq[cb][1], qq[cb][2], qq[cb][3]};
+                    *reinterpret_cast<f32x4*>(sc4 + cb * 12) = f32x4{ss[cb][0], ss[cb][1], ss[cb][2], ss[cb][3]};
+                    *reinterpret_cast<f32x4*>(sc4 + cb * 12 + 4) = f32x4{qq[cb][0], qq[cb][1], qq[cb][2], qq[cb][3]};
+                    *reinterpret_cast<f32x4*>(sc4 + cb * 12 + 8) = f32x4{kv[cb][0], kv[cb][1], kv[cb][2], kv[cb][3]};
                 }
             }
         }
         lds_barrier();                                     // every wave is done with the patch; the scratch is complete (stores in flight)
-        if (tid < 64) {                                    // tile partial (fixed order over the 4 waves)
-            const int co = tid >> 1, which = tid & 1, cb = co >> 4, gg = (co >> 2) & 3, i = co & 3;
-            float tot = 0.f;
+        if (tid < 32) {                                    // tile partial (fixed order over the 4 waves, rebased onto wave 0's pivot)
+            const int co = tid, cb = co >> 4, gg = (co >> 2) & 3, i = co & 3;
+            const float* s0 = scratch(0, gg) + cb * 12 + i;
+            f32x4 acc4 = f32x4{s0[0], s0[4], s0[8], 64.f};
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) tot += scratch(ww, gg)[cb * 8 + which * 4 + i];
-            a.part[((size_t)n * tpi + (t - n * tpi)) * 64 + tid] = tot;
+            for (int ww = 1; ww < 4; ++ww) {
+                const float* sw_ = scratch(ww, gg) + cb * 12 + i;
+                const float d = sw_[8] - acc4[2];
+                acc4[1] += sw_[4] + d * (2.f * sw_[0] + 64.f * d);
+                acc4[0] += sw_[0] + 64.f * d;
+                acc4[3] += 64.f;
+            }
+            *reinterpret_cast<f32x4*>(a.part + (((size_t)n * tpi + (t - n * tpi)) * 32 + co) * 4) = acc4;
         }
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)

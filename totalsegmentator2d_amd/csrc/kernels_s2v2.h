@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     const float oscale = *a.oscale;
     const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * sizeof(ST)), 0x00020000);
-    float st_s[NTW], st_q[NTW];
+    float st_s[NTW], st_q[NTW], st_k[NTW];
     TS2D_STAMP_AT(a.prof, 3)
     float bvs[NTW];       // every bias value before the first store: a load issued between stores waits (in-order vmcnt) for the stores ahead of it
 #pragma unroll
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     for (int nt = 0; nt < NTW; ++nt) {
         const int co = n0col + wn * (BN / 2) + nt * 32 + r;
         const float bv = bvs[nt];
+        const float kv = stat_pivot(round_act<ST>(__builtin_fmaf(acc_t[0][nt][0], oscale, bv)));      // shifted statistics (kernels.h)
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -227,29 +228,23 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
                 const unsigned soff = (unsigned)((((i & 3) + 8 * (i >> 2)) * a.Cout) * (int)sizeof(ST));      // scalar
                 float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
                 buffer_store_act<ST>(v, rsd, voff, soff);
-                v = round_act<ST>(v);                                            // statistics of what is stored
-                s += v; q = __builtin_fmaf(v, v, q);
+                const float d = round_act<ST>(v) - kv;                           // statistics of what is stored
+                s += d; q = __builtin_fmaf(d, d, q);
             }
         }
-        st_s[nt] = s; st_q[nt] = q;
+        st_s[nt] = s; st_q[nt] = q; st_k[nt] = kv;
     }
     TS2D_STAMP_AT(a.prof, 4)
     lds_barrier();                                         // every wave is done with the LDS images (the output stores stay in flight)
-    float* red = reinterpret_cast<float*>(smem8);          // [wm 4][column BN][2]
+    float* red = reinterpret_cast<float*>(smem8);          // [wm 4][column BN] x (S, Q, K, n)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         float s = st_s[nt], q = st_q[nt];
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-        if (h == 0) { const int c = wn * (BN / 2) + nt * 32 + r; red[(wm * BN + c) * 2] = s; red[(wm * BN + c) * 2 + 1] = q; }
+        if (h == 0) stat_wave_put(red, wm * BN + wn * (BN / 2) + nt * 32 + r, s, q, st_k[nt], 64.f);
     }
     lds_barrier();
-    if (tid < BN) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
-        float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
-        p[0] = s; p[1] = q;
-    }
+    if (tid < BN) stat_tile_store(red, 4, BN, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 4);
     TS2D_STAMP_AT(a.prof, 5)
     TS2D_PROF_FLUSH(a.prof)
 }

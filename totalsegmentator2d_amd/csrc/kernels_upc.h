@@ -16,7 +16,7 @@
 // owns parity class (A, B) = (w >> 1, w & 1), its two 32-row MFMA tiles are the 4 x 16 coarse positions (I, J) of the tile, i.e.
 // output pixels (2I + A, 2J + B).  Phase 1 walks the coarse channels in chunks of 32 (2 k-steps x 4 "taps" (dI, dJ) per wave: 96 MFMAs
 // for BN = 64 between two barriers), phase 2 the skip channels with the ordinary 9 taps (patch columns stored even-first / odd-second so that the
-// stride-2 pixel walk of a fragment is a walk over consecutive LDS slots).  k-group-major planes as in kernels_f16x3_p.h; row
+// stride-2 pixel walk of a fragment is a walk over consecutive LDS slots).  k-group-major planes as in kernels_f16x3_qp.h; row
 // pitches (32 / 40 slots) chosen so that the two 16-lane runs of a fragment read fall on disjoint slot residues.
 #pragma once
 #include "kernels_f16x3_one.h"
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
     const size_t img_el = (size_t)a.H * a.W * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(a.dst + (size_t)nimg0 * img_el, 0, (int)(img_el * 4), 0x00020000);
     const bool edge = tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1;       // wave-uniform
-    float st_s[NT], st_q[NT];
+    float st_s[NT], st_q[NT], st_k[NT];
     // bias variants of this lane's channels, all loaded before the first store (a load per element serialised the 64 stores of a
     // wave behind 64 round trips to memory: measured 35 000 cycles per workgroup, in-kernel stamps of gpurun r2 upc_ph3; a load
     // between stores still waits - in-order vmcnt - for the stores ahead of it)
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
+        const float kv = stat_pivot(__builtin_fmaf(acc_t[0][nt][0], oscale, bv4[nt]));      // shifted statistics (kernels.h); any finite pivot near the data
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
                     const unsigned soff = (unsigned)(((2 * dI * a.W + 2 * dJ) * a.Cout) * 4);      // scalar
                     const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv4[nt]);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
-                    s += v; q = __builtin_fmaf(v, v, q);
+                    const float d = v - kv;
+                    s += d; q = __builtin_fmaf(d, d, q);
                 }
             } else {
 #pragma unroll
@@ -375,11 +377,12 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
                     const float bv = X == 0 ? b0 : (X == a.W - 1 ? b2 : b1);
                     const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
-                    s += v; q = __builtin_fmaf(v, v, q);
+                    const float d = v - kv;
+                    s += d; q = __builtin_fmaf(d, d, q);
                 }
             }
         }
-        st_s[nt] = s; st_q[nt] = q;
+        st_s[nt] = s; st_q[nt] = q; st_k[nt] = kv;
     }
     TS2D_STAMP(4)
     lds_barrier();
@@ -388,18 +391,12 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
     for (int nt = 0; nt < NT; ++nt) {
         float s = st_s[nt], q = st_q[nt];
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-        if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
+        if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], 64.f);
     }
     TS2D_STAMP(5)
     lds_barrier();
     TS2D_STAMP(6)
-    if (tid < BN) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
-        float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
-        p[0] = s; p[1] = q;
-    }
+    if (tid < BN) stat_tile_store(red, 4, BN, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 4);
     TS2D_PROF_FLUSH(a.prof)
 #undef TS2D_STAMP
 }

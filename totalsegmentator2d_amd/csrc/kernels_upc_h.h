@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
     const size_t img_el = (size_t)a.H * a.W * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * 2), 0x00020000);
     const bool edge = tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1;       // wave-uniform
-    float st_s[NT], st_q[NT];
+    float st_s[NT], st_q[NT], st_k[NT];
     float bv0[NT], bv1[NT], bv2[NT], bv3[NT], bv4[NT], bv5[NT], bv6[NT], bv7[NT], bv8[NT];       // (nine arrays: see kernels_upc.h)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
+        const float kv = stat_pivot(round_act<ST>(__builtin_fmaf(acc_t[0][nt][0], oscale, bv4[nt])));      // shifted statistics (kernels.h)
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -265,11 +266,11 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
                 }
                 float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
                 buffer_store_act<ST>(v, rsd, voff, soff);
-                v = round_act<ST>(v);                                                // statistics of what is stored
-                s += v; q = __builtin_fmaf(v, v, q);
+                const float d = round_act<ST>(v) - kv;                               // statistics of what is stored
+                s += d; q = __builtin_fmaf(d, d, q);
             }
         }
-        st_s[nt] = s; st_q[nt] = q;
+        st_s[nt] = s; st_q[nt] = q; st_k[nt] = kv;
     }
     lds_barrier();
     float* red = reinterpret_cast<float*>(smem8);
@@ -277,16 +278,10 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
     for (int nt = 0; nt < NT; ++nt) {
         float s = st_s[nt], q = st_q[nt];
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-        if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
+        if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], 64.f);
     }
     lds_barrier();
-    if (tid < BN) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
-        float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
-        p[0] = s; p[1] = q;
-    }
+    if (tid < BN) stat_tile_store(red, 4, BN, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 4);
 }
 
 }  // namespace ts2d

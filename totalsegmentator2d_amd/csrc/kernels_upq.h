@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kUqThreads, 1) void conv3x3_upq(const UpcArgs a) {
                     acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][mt][0], fb[cur][nt][0], acc_c[mt][nt], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0); }
             TS2D_LOAD_FRAGS(0, 0)
-            // (memory operations of a chunk: every use of a loaded register first, THEN the weight DMA - see kernels_f16x3_q.h)
+            // (memory operations of a chunk: every use of a loaded register first, THEN the weight DMA - see kernels_f16x3_qp.h)
             TS2D_TAP(0, convert(0, ch1, pb_next);)
             TS2D_TAP(1, convert(1, ch1, pb_next);)
             TS2D_TAP(2, convert(2, ch1, pb_next);)
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kUqThreads, 1) void conv3x3_upq(const UpcArgs a) {
     const size_t img_el = (size_t)a.H * a.W * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(a.dst + (size_t)nimg0 * img_el, 0, (int)(img_el * 4), 0x00020000);
     const bool edge = tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1;       // wave-uniform
-    float st_s[NT], st_q[NT];
+    float st_s[NT], st_q[NT], st_k[NT];
     float bv0[NT], bv1[NT], bv2[NT], bv3[NT], bv4[NT], bv5[NT], bv6[NT], bv7[NT], bv8[NT];       // (see kernels_upc.h)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -326,6 +326,7 @@ __global__ __launch_bounds__(kUqThreads, 1) void conv3x3_upq(const UpcArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
+        const float kv = stat_pivot(__builtin_fmaf(acc_t[0][nt][0], oscale, bv4[nt]));      // shifted statistics (kernels.h)
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -338,7 +339,8 @@ __global__ __launch_bounds__(kUqThreads, 1) void conv3x3_upq(const UpcArgs a) {
                     const unsigned soff = (unsigned)(((4 * dI * a.W + 2 * dJ) * a.Cout) * 4);      // scalar
                     const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv4[nt]);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
-                    s += v; q = __builtin_fmaf(v, v, q);
+                    const float d = v - kv;
+                    s += d; q = __builtin_fmaf(d, d, q);
                 }
             } else {
 #pragma unroll
@@ -353,11 +355,12 @@ __global__ __launch_bounds__(kUqThreads, 1) void conv3x3_upq(const UpcArgs a) {
                     const float bv = X == 0 ? b0 : (X == a.W - 1 ? b2 : b1);
                     const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, voff, soff, 0);
-                    s += v; q = __builtin_fmaf(v, v, q);
+                    const float d = v - kv;
+                    s += d; q = __builtin_fmaf(d, d, q);
                 }
             }
         }
-        st_s[nt] = s; st_q[nt] = q;
+        st_s[nt] = s; st_q[nt] = q; st_k[nt] = kv;
     }
     TS2D_STAMP_AT(a.prof, 4)
     float* red = reinterpret_cast<float*>(smem8);           // (all LDS reads ended at the loop's last barrier)
@@ -365,16 +368,10 @@ __global__ __launch_bounds__(kUqThreads, 1) void conv3x3_upq(const UpcArgs a) {
     for (int nt = 0; nt < NT; ++nt) {
         float s = st_s[nt], q = st_q[nt];
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-        if (h == 0) { red[(w * BN + nt * 32 + r) * 2] = s; red[(w * BN + nt * 32 + r) * 2 + 1] = q; }
+        if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], 64.f);
     }
     lds_barrier();
-    if (tid < BN) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 8; ++ww) { s += red[(ww * BN + tid) * 2]; q += red[(ww * BN + tid) * 2 + 1]; }
-        float* p = a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 2;
-        p[0] = s; p[1] = q;
-    }
+    if (tid < BN) stat_tile_store(red, 8, BN, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 4);
     TS2D_STAMP_AT(a.prof, 5)
     TS2D_PROF_FLUSH(a.prof)
 }
