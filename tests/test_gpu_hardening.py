@@ -75,7 +75,7 @@ def test_large_conv_biases_are_dead_under_instance_norm(gain):
 
 
 def test_input_offset_puts_the_mean_far_above_sigma_at_the_first_layer():
-    """A network input with an offset of 50 sigma gives the first conv's raw output |mean| / sigma of 0 ... 35 per channel (the
+    """A network input with an offset of 50 sigma gives the first conv's raw output |mean| / sigma of up to ~20 per channel (the zero-padded border bounds it) (the
     same happens to any layer whose input statistics drift): torch normalises with mean first, then sum((x - mean)^2).  The
     normalised activation of enc0.c0 and the logits must follow the oracle."""
     arch, sd, x = _wide_case()
@@ -83,7 +83,7 @@ def test_input_offset_puts_the_mean_far_above_sigma_at_the_first_layer():
     ref, inter = O.unet_forward(arch, sd, xo, return_intermediates=True)
     raw = O.F.conv2d(O._t(xo), O._t(sd['encoder.stages.0.0.convs.0.conv.weight']), O._t(sd['encoder.stages.0.0.convs.0.conv.bias']), padding=1).numpy()
     ratio = np.abs(raw.mean(axis=(2, 3))) / raw.std(axis=(2, 3))
-    assert ratio.max() >= 25.0                                                 # the regime this test is about
+    assert ratio.max() >= 15.0                                                 # the regime this test is about
     with Engine(arch, weights.pack_blob(arch, sd)) as e:
         for mode in ('split', 'exact'):
             e.set_precision(mode)
