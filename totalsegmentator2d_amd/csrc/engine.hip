@@ -9,6 +9,7 @@
 #include "kernels_head.h"
 #include "kernels_f16x3_one.h"
 #include "kernels_f16x3_qp.h"
+#include "kernels_f16x3_qp16.h"
 #include "kernels_first.h"
 #include "kernels_res32.h"
 #include "kernels_s2v2.h"
@@ -126,6 +127,8 @@ struct ts2d_engine {
     int dbg = 0;                  // TS2D_DBG: timing ablations (diagnostic runs only)
     bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
     bool use_q = true;            // persistent 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (TS2D_Q=0 falls back to conv3x3_f16x3_one)
+    int q16_var = 0;              // TS2D_Q16V: experiment switches of conv3x3_f16x3_qp16
+    bool use_q16 = false;         // TS2D_Q16=1: ... on v_mfma_f32_16x16x32_f16 (conv3x3_f16x3_qp16: measured 1.5-10 % slower than the 32x32x16 form, opt-in)
     bool use_upq = true;          // 512-thread double-buffered variant of the composed block on 16 x 32 tiles (TS2D_UPQ=0: conv3x3_upc)
     bool use_upc = true;          // decoder c0 blocks composed with their transposed conv (TS2D_UPC=0 falls back to two kernels)
     unsigned long long* d_prof = nullptr;     // TS2D_DBG=256: in-kernel phase counters, 8 per op (diagnostic)
@@ -1067,10 +1070,19 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 ca.lg_tx = lg_exact(ca.tiles_x); ca.lg_tpi = lg_exact(ca.tiles_x * ca.tiles_y);
                 const int gridq = (ca.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
                 const int gridp = std::min(gridq, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));     // one persistent workgroup per CU
-                static std::atomic<uint64_t> doneqp{0};
-                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp), doneqp));
-                hipLaunchKernelGGL(conv3x3_f16x3_qp, dim3(gridp), dim3(kQThreads), kQpLds, st, ca);
-                le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp");
+                if (e->use_q16) {
+#define TS2D_Q16_LAUNCH(V_) do { static std::atomic<uint64_t> done_{0}; \
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp16<V_>), done_)); \
+                    hipLaunchKernelGGL(conv3x3_f16x3_qp16<V_>, dim3(gridp), dim3(kQThreads), kQ16Lds, st, ca); } while (0)
+                    if (e->q16_var & 1) TS2D_Q16_LAUNCH(1); else TS2D_Q16_LAUNCH(0);
+#undef TS2D_Q16_LAUNCH
+                    le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp16");
+                } else {
+                    static std::atomic<uint64_t> doneqp{0};
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp), doneqp));
+                    hipLaunchKernelGGL(conv3x3_f16x3_qp, dim3(gridp), dim3(kQThreads), kQpLds, st, ca);
+                    le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp");
+                }
             } else if (one) {     // tile inside one image: lean staging path
                 le = launch_one(bn, ca, grid, smem, st); prof_kernel(e, bn == 64 ? "conv3x3_f16x3_one<64>" : "conv3x3_f16x3_one<32>");
             } else if (one_s2) {
@@ -1167,6 +1179,8 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_RES")) e->use_res = getenv("TS2D_RES")[0] == '1';
         if (getenv("TS2D_S2V2")) e->use_s2v2 = getenv("TS2D_S2V2")[0] == '1';
         if (getenv("TS2D_Q")) e->use_q = getenv("TS2D_Q")[0] == '1';
+        if (getenv("TS2D_Q16")) e->use_q16 = getenv("TS2D_Q16")[0] == '1';
+        if (getenv("TS2D_Q16V")) e->q16_var = atoi(getenv("TS2D_Q16V"));
         if (getenv("TS2D_UPQ")) e->use_upq = getenv("TS2D_UPQ")[0] == '1';
         if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
