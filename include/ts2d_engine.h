@@ -132,6 +132,15 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
 #define TS2D_TILE_F16 1
 int ts2d_engine_set_tile_dtype(ts2d_engine* e, int mode);
 
+/* Activation memory (ABI 5).  By default the activations of a forward share one arena by LIVENESS: a tensor's bytes are reused once
+ * its last reader has run (the encoder skips live until their decoder block) - ~110 instead of ~340 MB per 2x512x512 slice of the
+ * canonical net.  enable != 0 gives every tensor its own buffer again: needed before a forward whose intermediate tensors are to be
+ * read back with ts2d_engine_debug_tensor (a reused tensor reports TS2D_ERR_STATE there).  ts2d_engine_check needs no switch: when a
+ * synchronous call flagged inf / NaN it re-runs that input once with private buffers to name the first bad layer.  Takes effect at
+ * the next ts2d_engine_reserve / forward.  (The reference keeps every intermediate alive only as long as torch's autograd-free
+ * forward does: ts2d/core/inference/prediction_worker.py:209.) */
+int ts2d_engine_set_keep_activations(ts2d_engine* e, int enable);
+
 /* 1 if the last ts2d_engine_predict_tiled call produced an infinite aggregated float16 logit - upstream's
  * "Encountered inf in predicted array" check of predict_sliding_window_return_logits (reached from
  * ts2d/core/inference/prediction_worker.py:209), evaluated on the device instead of a host pass over the array. */

@@ -40,6 +40,8 @@ class Engine:
         self.lib = _lib.load()
         self.arch = arch
         self.device = int(device)
+        self._keep = False           # one buffer per activation (debug access); default: buffers shared by liveness
+        self._last = None            # arguments of the last forward (debug_tensor re-runs it with private buffers)
         self._h = ctypes.c_void_p()
         d = _desc(arch)
         if blob is not None:
@@ -94,6 +96,12 @@ class Engine:
         m = {'float': 0, 'half': 1}.get(mode, mode)
         _lib.check(self.lib.ts2d_engine_set_tile_dtype(self._h, int(m)), 'ts2d_engine_set_tile_dtype')
 
+    def keep_activations(self, on: bool = True):
+        """One buffer per activation (C-ABI ts2d_engine_set_keep_activations) instead of liveness-based sharing; needed to read
+        intermediate tensors back with :meth:`debug_tensor` (which switches it on itself and re-runs the last forward)."""
+        _lib.check(self.lib.ts2d_engine_set_keep_activations(self._h, int(bool(on))), 'ts2d_engine_set_keep_activations')
+        self._keep = bool(on)
+
     # ------------------------------------------------------------------ forward
     def reserve(self, B: int, H: int, W: int):
         _lib.check(self.lib.ts2d_engine_reserve(self._h, B, H, W), 'ts2d_engine_reserve')
@@ -102,6 +110,7 @@ class Engine:
         """x: [B,C,H,W] fp32, numpy (host) or torch CUDA tensor (device, zero-copy).
         Returns (logits or None, packed mask or None) of the same kind as x."""
         K = self.arch.num_classes
+        self._last = (x, logits, mask)
         if _is_torch(x):
             import torch
             if not x.is_cuda:
@@ -205,7 +214,16 @@ class Engine:
         return {self.lib.ts2d_engine_op_name(self._h, i).decode(): self.lib.ts2d_engine_op_kernel(self._h, i).decode() for i in range(n)}
 
     def debug_tensor(self, name: str, capacity: int = 1 << 26) -> np.ndarray:
-        """Test accessor: activation `name` of the last forward as torch would hold it (NCHW, norm+act applied)."""
+        """Test accessor: activation `name` of the last forward as torch would hold it (NCHW, norm+act applied).  Activations
+        share buffers by liveness: the first call switches the engine to private buffers and runs the last forward again."""
+        if not self._keep:
+            self.keep_activations(True)
+            if self._last is not None:
+                x, lg, mk = self._last
+                self.forward(x, logits=lg, mask=mk)
+                if _is_torch(x):
+                    import torch
+                    torch.cuda.synchronize(x.device)
         out = np.empty(capacity, dtype=np.float32)
         dims = (ctypes.c_int32 * 4)()
         _lib.check(self.lib.ts2d_engine_debug_tensor(self._h, name.encode(), out.ctypes.data, out.size, ctypes.byref(dims)),
