@@ -395,8 +395,8 @@ def test_config3_full_model_set_batch128_f16():
 
 def test_activation_buffers_are_shared_by_liveness():
     """The activations of a forward share ONE arena by liveness (include/ts2d_engine.h, ABI 5): same logits bit for bit as with
-    one buffer per tensor, a third of the memory; an intermediate tensor whose bytes were recycled is refused by the C-ABI until
-    ts2d_engine_set_keep_activations(1) (the Python accessor switches it on and re-runs)."""
+    one buffer per tensor, a third of the activation memory; an intermediate tensor whose bytes were recycled is refused by the
+    C-ABI until ts2d_engine_set_keep_activations(1) (the Python accessor switches it on and re-runs)."""
     import ctypes
     from totalsegmentator2d_amd import _lib
     from totalsegmentator2d_amd.arch import UNetArch
@@ -404,17 +404,21 @@ def test_activation_buffers_are_shared_by_liveness():
     sd, blob = blob_for(arch, 91)
     x = cases.make_input(arch, 2, 256, 256, 91)
     with Engine(arch, blob) as e:
-        for mode in ('split', 'exact', 'f16'):               # the plan is remade per mode (the composed decoder entries differ)
-            e.keep_activations(False)
+        a, ma = e.forward(x, logits=True, mask=True)
+        shared = e.device_bytes() - e.weight_buffer()[1]          # workspace only (device_bytes is the allocation's high-water mark)
+        out = np.empty(1 << 24, np.float32); dims = (ctypes.c_int32 * 4)()
+        rc = e.lib.ts2d_engine_debug_tensor(e._h, b'enc1.c1', out.ctypes.data, out.size, ctypes.byref(dims))
+        assert rc != 0 and 'overwritten' in _lib.last_error()
+        e.keep_activations(True)
+        b, mb = e.forward(x, logits=True, mask=True)
+        private = e.device_bytes() - e.weight_buffer()[1]
+        assert np.array_equal(a, b) and np.array_equal(ma, mb)
+        assert e.debug_tensor('enc1.c1').shape == (2, 64, 128, 128)
+        assert shared < 0.62 * private, (shared, private)         # (the workspace also holds the staged input / logits / masks)
+        for mode in ('exact', 'f16'):                             # the plan is remade per mode (the composed decoder entries differ)
             e.set_precision(mode)
+            e.keep_activations(False)
             a, ma = e.forward(x, logits=True, mask=True)
-            shared = e.device_bytes() - e.weight_buffer()[1]          # workspace only
-            out = np.empty(1 << 24, np.float32); dims = (ctypes.c_int32 * 4)()
-            rc = e.lib.ts2d_engine_debug_tensor(e._h, b'enc1.c1', out.ctypes.data, out.size, ctypes.byref(dims))
-            assert rc != 0 and 'overwritten' in _lib.last_error()
             e.keep_activations(True)
             b, mb = e.forward(x, logits=True, mask=True)
-            private = e.device_bytes() - e.weight_buffer()[1]
             assert np.array_equal(a, b) and np.array_equal(ma, mb), mode
-            assert e.debug_tensor('enc1.c1').shape == (2, 64, 128, 128)
-            assert shared < 0.62 * private, (mode, shared, private)      # (the workspace also holds the staged input / logits / masks)

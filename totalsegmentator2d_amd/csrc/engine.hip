@@ -1060,13 +1060,18 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 // stride-2 block on full 8 x 32 output tiles: one 512-thread workgroup per CU, up to 128 output columns
                 ca.n_ctiles = op.cout / op.bn2; ca.lg_nct = lg_exact(ca.n_ctiles);
                 ca.wph = wts + op.dev_w2; ca.oscale = wts + op.dev_ws; ca.part = e->d_part;
-                const int grid2 = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
                 const int npp = f16 ? 1 : 2;
-                const size_t smem2 = (size_t)npp * 2 * kS2Plane + (size_t)9 * npp * 2 * op.bn2 * 16;
+                // persistent: one workgroup per CU walks its tiles; every chunk's weights resident in LDS when they fit beside the patch
+                const size_t wchunk = (size_t)9 * npp * 2 * op.bn2 * 16;
+                const bool resw = (size_t)npp * 2 * kS2Plane + (size_t)(op.cin / 16) * wchunk <= (size_t)160 * 1024;
+                const int grid2 = std::min((g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));
+                const size_t smem2 = (size_t)npp * 2 * kS2Plane + (resw ? (size_t)(op.cin / 16) : 1) * wchunk;
                 TRY(prof_begin(e, op.name, st)); prof_kernel(e, op.bn2 == 128 ? "conv3x3s2_v2<128>" : "conv3x3s2_v2<64>");
-#define TS2D_S2V2_LAUNCH(BN_, ST_, NP_) do { static std::atomic<uint64_t> done_{0}; \
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_>), done_)); \
-                    hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } while (0)
+#define TS2D_S2V2_LAUNCH(BN_, ST_, NP_) do { static std::atomic<uint64_t> done_{0}, doner_{0}; \
+                    if (resw) { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, true>), doner_)); \
+                                hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, true>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } \
+                    else { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, false>), done_)); \
+                           hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, false>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } } while (0)
                 if (op.bn2 == 128) { if (f16) TS2D_S2V2_LAUNCH(128, _Float16, 1); else TS2D_S2V2_LAUNCH(128, float, 3); }
                 else { if (f16) TS2D_S2V2_LAUNCH(64, _Float16, 1); else TS2D_S2V2_LAUNCH(64, float, 3); }
 #undef TS2D_S2V2_LAUNCH
