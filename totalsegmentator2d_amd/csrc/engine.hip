@@ -983,7 +983,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             ua.tiles_x = Wt / 32; ua.tiles_y = Ht / 8; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y; ua.n_ctiles = op.cout / bn;
             ua.lg_nct = ilog2(ua.n_ctiles); ua.lg_tx = ilog2(ua.tiles_x); ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
             ua.slope = a.leaky_slope;
-            ua.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
+            ua.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr; ua.dbg = e->dbg;
             const int grid = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
             const size_t smem_u = std::max((size_t)8 * kUcPlane, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
             auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };

@@ -152,6 +152,9 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc_t[mt][nt][i] = 0.f;
 
+    // static issue priority for the second-dispatched half of the workgroup (guide, "Two waves per SIMD" item 4: the younger wave of a
+    // SIMD loses every VALU arbitration to the older one); measured (gpurun r3, scripts/gpu_ab.py): 2.5-5 % per layer, off: TS2D_DBG=512
+    if (!(a.dbg & 512)) { if (w >= 4) __builtin_amdgcn_s_setprio(1); }
     const int nitems = ntl * nchunks;
     for (int i = 0; i < nitems; ++i) {
         const int b = i & 1;

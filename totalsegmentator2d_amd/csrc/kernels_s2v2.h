@@ -154,6 +154,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
 
     TS2D_PROF_DECL(a.prof);
     const int nitems = ntl * nchunks;
+    const bool younger = w >= 4 && !(a.dbg & 512);         // static issue priority for waves 4-7 (kernels_f16x3_qp.h): restored after every MFMA phase
     auto item = [&](Stage& S) {                            // one (tile, chunk) item: conversion from S, next request into S, MFMAs, epilogue
         int nimg0, tyi, txi, tin;
         tile_origin(cur.k, nimg0, tyi, txi, tin);
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        if (younger) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll

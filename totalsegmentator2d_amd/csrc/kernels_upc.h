@@ -35,6 +35,7 @@ struct UpcArgs {
     int tiles_x, tiles_y, n_mtiles, n_ctiles, lg_nct, lg_tx, lg_tpi;
     float slope;
     unsigned long long* prof;   // diagnostic: phase cycle counters (6 entries) or nullptr
+    int dbg;                    // experiment switches (TS2D_DBG; 0 in production)
 };
 
 constexpr int kUcPitch = 32, kUcSlots = 6 * kUcPitch, kUcPlane = kUcSlots * 16;        // coarse patch: 6 rows x 18 (pitch 32) slots

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(kUqThreads, 1) void conv3x3_upq(const UpcArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+    if (!(a.dbg & 512)) { if (w >= 4) __builtin_amdgcn_s_setprio(1); }      // static issue priority for waves 4-7 (kernels_f16x3_qp.h; here within noise)
     const int pA = (w >> 1) & 1, pB = w & 1, hw = w >> 2;   // this wave's output parity and half of the coarse rows
     const int r = lane & 31, h = lane >> 5;
     const int octi = (lane >> 3) & 1, oct = octi * 8;
