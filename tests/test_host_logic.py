@@ -101,3 +101,68 @@ def test_randomised_window_configurations_match_the_torch_pipeline():
         out = out.cpu().numpy() if hasattr(out, 'cpu') else out
         ref = O.predict_logits(arch, sds, data, patch, step, mirror, tile_dtype=order).numpy()
         assert out.dtype == np.float16 and np.array_equal(out, ref), (t, feats, shape, patch, step, mirror, folds, order)
+
+
+def test_normalisation_schemes_of_the_preprocessor():
+    """SURVEY row A1, the branches beside the plain z-score: masked ZScoreNormalization (statistics inside the non-zero mask,
+    the outside stays 0), CTNormalization (clip to the dataset percentiles, dataset mean / std), Rescale / RGB / No normalisation."""
+    from types import SimpleNamespace
+    from totalsegmentator2d_amd import preprocess as P
+    rng = np.random.default_rng(11)
+    img = rng.normal(200, 80, (1, 40, 50)).astype(np.float32)
+    img[:, :8] = 0; img[:, :, :5] = 0                                    # a zero frame: nnU-Net crops to the non-zero box first
+    img[0, 20, 20] = 0                                                   # ... and a zero INSIDE the box: outside the mask
+    data = img[None]                                                     # [C=1, Z=1, H, W]
+    pm = SimpleNamespace(transpose_forward=[0, 1, 2], plans={'foreground_intensity_properties_per_channel': {
+        '0': {'mean': 180.0, 'std': 70.0, 'percentile_00_5': 20.0, 'percentile_99_5': 400.0}}})
+    cm = SimpleNamespace(spacing=(1.5, 1.5), normalization_schemes=['ZScoreNormalization'], use_mask_for_norm=[True])
+    out, _, props = P.DefaultPreprocessor(False).run_case_npy(data.copy(), None, {'spacing': (999.0, 1.5, 1.5)}, pm, cm, {})
+    assert props['bbox_used_for_cropping'] == [[0, 1], [8, 40], [5, 50]] and out.shape == (1, 1, 32, 45)
+    crop = img[:, 8:, 5:]
+    m = crop != 0
+    ref = np.zeros_like(crop); ref[m] = (crop[m] - crop[m].mean()) / max(crop[m].std(), 1e-8)
+    assert np.array_equal(out[0], ref) and out[0, 0, 12, 15] == 0.0        # the inner zero is outside the mask: untouched
+    cm.normalization_schemes, cm.use_mask_for_norm = ['CTNormalization'], [False]
+    out, _, _ = P.DefaultPreprocessor(False).run_case_npy(data.copy(), None, {'spacing': (999.0, 1.5, 1.5)}, pm, cm, {})
+    assert np.allclose(out[0], (np.clip(crop, 20.0, 400.0) - 180.0) / 70.0, atol=1e-6)
+    x = rng.integers(0, 256, (30, 20)).astype(np.float32)
+    assert np.allclose(P.normalize_channel(x, 'RGBTo01Normalization', False, None, None), x / 255.0)
+    r = P.normalize_channel(x, 'RescaleTo01Normalization', False, None, None)
+    assert r.min() == 0.0 and abs(r.max() - 1.0) < 1e-6
+    assert np.array_equal(P.normalize_channel(x, 'NoNormalization', False, None, None), x)
+    with pytest.raises(NotImplementedError):
+        P.normalize_channel(x, 'SomethingElse', False, None, None)
+
+
+def test_resampling_to_the_plan_spacing_and_back():
+    """an image whose spacing differs from the plan's is resampled in-plane (order 3, after normalising) to
+    round(shape * spacing / target), the logits are resampled back (order 1) before the threshold.  The primitive restates
+    skimage.transform.resize(mode='edge', anti_aliasing=False) = scipy.ndimage.zoom(grid_mode=True, mode='nearest') + range clip."""
+    from types import SimpleNamespace
+    from totalsegmentator2d_amd import preprocess as P, export as E
+    # grid_mode zoom by 2, order 1: output sample k sits at input coordinate (k + 0.5) / 2 - 0.5 (edge-clamped)
+    ramp = np.arange(8, dtype=np.float32)[None, :].repeat(3, 0)
+    up = P.resize_like_skimage(ramp, (3, 16), 1)
+    exp = np.clip((np.arange(16) + 0.5) / 2 - 0.5, 0, 7).astype(np.float32)
+    assert up.shape == (3, 16) and np.allclose(up[1], exp, atol=1e-6)
+    assert np.array_equal(P.resize_like_skimage(ramp, (3, 8), 3), ramp)                       # same shape: untouched
+    c = np.full((10, 12), 3.25, np.float32)
+    assert np.allclose(P.resize_like_skimage(c, (17, 9), 3), 3.25)                              # constants stay constant
+    rng = np.random.default_rng(12)
+    z = rng.normal(0, 1, (20, 24)).astype(np.float32)
+    big = P.resize_like_skimage(z, (40, 48), 3)
+    assert big.min() >= z.min() and big.max() <= z.max()                                       # clip=True: no spline overshoot
+    # through the preprocessor and the exporter: 3.0 mm image, 1.5 mm plan
+    data = rng.normal(100, 30, (2, 1, 50, 30)).astype(np.float32)
+    pm = SimpleNamespace(transpose_forward=[0, 1, 2], transpose_backward=[0, 1, 2], plans={})
+    cm = SimpleNamespace(spacing=(1.5, 1.5), normalization_schemes=None, use_mask_for_norm=None)
+    out, _, props = P.DefaultPreprocessor(False).run_case_npy(data.copy(), None, {'spacing': (999.0, 3.0, 3.0)}, pm, cm, {})
+    assert out.shape == (2, 1, 100, 60) and props['shape_after_cropping_and_before_resampling'] == (1, 50, 30)
+    assert np.allclose(out[0, 0], P.resize_like_skimage(P.zscore(data[0])[0], (100, 60), 3))   # normalised FIRST, then resampled
+    logits = np.where(out[:1] > 0, 2.0, -2.0).astype(np.float16)                               # [K=1, 1, 100, 60]
+    seg = E.convert_predicted_logits_to_segmentation_with_correct_shape(logits, props, True, [0, 1, 2])
+    assert seg.shape == (1, 1, 50, 30) and seg.dtype == np.uint8
+    back = P.resample_data_to_shape(logits.astype(np.float32), (1, 50, 30), order=1)
+    assert np.array_equal(seg, (back > E.SIGMOID_HALF_THRESHOLD).astype(np.uint8))
+    with pytest.raises(NotImplementedError):
+        P.resample_data_to_shape(np.zeros((1, 2, 8, 8), np.float32), (4, 8, 8))               # slice axis: 3-D configurations only

@@ -21,9 +21,14 @@ SIGMOID_HALF_THRESHOLD = np.float32(1.5 * 2.0 ** -24)     # sigmoid(float32 x) >
 def convert_predicted_logits_to_segmentation_with_correct_shape(logits, properties: dict, multilabel: bool = True,
                                                                 transpose_backward=(0, 1, 2)) -> np.ndarray:
     """[K, Z, H, W] logits (any float dtype) -> uint8 segmentation in the ORIGINAL (pre-crop) array shape:
-    multilabel: [K, Z0, H0, W0] of {0,1}; otherwise a label map [Z0, H0, W0] (argmax).  The resampling step of upstream
-    is a no-op for the shapes this engine accepts (preprocess.py refuses spacing changes)."""
+    multilabel: [K, Z0, H0, W0] of {0,1}; otherwise a label map [Z0, H0, W0] (argmax).  Upstream first resamples the logits back to
+    ``properties['shape_after_cropping_and_before_resampling']`` (``resampling_fn_probabilities``: order 1, per slice for the 2-D
+    configurations [UPSTREAM-RECALL]) - a no-op when the plan's spacing is the image's."""
     lg = np.asarray(logits)
+    tgt = tuple(properties.get('shape_after_cropping_and_before_resampling', lg.shape[1:]))
+    if tuple(lg.shape[1:]) != tgt:
+        from .preprocess import resample_data_to_shape
+        lg = resample_data_to_shape(lg.astype(np.float32), tgt, order=1)
     shape0 = tuple(properties['shape_before_cropping'])
     bbox = properties['bbox_used_for_cropping']
     sl = tuple(slice(b[0], b[1]) for b in bbox)

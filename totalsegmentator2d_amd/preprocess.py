@@ -64,8 +64,10 @@ def read_images(files: Sequence[str]) -> Tuple[np.ndarray, dict]:
     return data, {'spacing': spacing, 'sitk_stuff': stuff}
 
 
-def crop_to_nonzero(data: np.ndarray):
-    """``crop_to_nonzero``: bounding box of voxels that are non-zero in ANY channel."""
+def crop_to_nonzero(data: np.ndarray, return_mask: bool = False):
+    """``crop_to_nonzero``: bounding box of voxels that are non-zero in ANY channel.  ``return_mask``: also the non-zero mask inside
+    the box - upstream writes it into the segmentation (``seg = where(nonzero_mask, 0, -1)``) and the masked normalisers use
+    ``seg >= 0``."""
     nz = np.any(data != 0, axis=0)
     if not nz.any():
         bbox = [[0, s] for s in data.shape[1:]]
@@ -76,6 +78,8 @@ def crop_to_nonzero(data: np.ndarray):
             idx = np.where(nz.any(axis=other))[0]
             bbox.append([int(idx[0]), int(idx[-1]) + 1])
     sl = (slice(None),) + tuple(slice(b[0], b[1]) for b in bbox)
+    if return_mask:
+        return data[sl], bbox, nz[sl[1:]]
     return data[sl], bbox
 
 
@@ -86,6 +90,74 @@ def zscore(img: np.ndarray) -> np.ndarray:
     img -= mean
     img /= max(std, 1e-8)
     return img
+
+
+def normalize_channel(img: np.ndarray, scheme: str, use_mask: bool, mask: Optional[np.ndarray], props: Optional[dict]) -> np.ndarray:
+    """nnU-Net ``default_normalization_schemes`` [UPSTREAM-RECALL nnunetv2 2.6], float32 like upstream's ``target_dtype``:
+    ZScoreNormalization (optionally inside the non-zero mask only: outside stays 0), CTNormalization (clip to the dataset's
+    0.5 / 99.5 percentiles, then the dataset's mean / std: ``plans['foreground_intensity_properties_per_channel'][str(c)]``),
+    NoNormalization, RescaleTo01Normalization, RGBTo01Normalization."""
+    img = img.astype(np.float32, copy=True)
+    if scheme == 'ZScoreNormalization':
+        if use_mask:
+            if mask is None:
+                raise RuntimeError("masked ZScoreNormalization needs the non-zero mask")
+            m = mask.astype(bool)
+            mean, std = img[m].mean(), img[m].std()
+            img[m] = (img[m] - mean) / max(std, 1e-8)
+            return img
+        return zscore(img)
+    if scheme == 'CTNormalization':
+        if not props:
+            raise RuntimeError("CTNormalization needs plans['foreground_intensity_properties_per_channel']")
+        lo, hi = props['percentile_00_5'], props['percentile_99_5']
+        np.clip(img, lo, hi, out=img)
+        img -= np.float32(props['mean'])
+        img /= np.float32(max(props['std'], 1e-8))
+        return img
+    if scheme == 'NoNormalization':
+        return img
+    if scheme == 'RescaleTo01Normalization':
+        img -= img.min()
+        img /= np.clip(img.max(), a_min=1e-8, a_max=None)
+        return img
+    if scheme == 'RGBTo01Normalization':
+        if img.min() < 0 or img.max() > 255:
+            raise RuntimeError("RGB images are uint 8, for whatever reason I found pixel values outside [0, 255]")
+        return img / np.float32(255.0)
+    raise NotImplementedError(f"normalization scheme {scheme} is not implemented")
+
+
+def resize_like_skimage(img2d: np.ndarray, new_shape, order: int) -> np.ndarray:
+    """``skimage.transform.resize(img, new_shape, order, mode='edge', anti_aliasing=False)`` of scikit-image >= 0.19 (nnU-Net's
+    resampling primitive) restated with scipy, which is what skimage calls itself on this path [UPSTREAM-RECALL]:
+    ``ndi.zoom(img, out / in, order, mode='nearest', grid_mode=True)`` followed by a clip to the input's value range
+    (``clip=True``).  skimage is not installed here."""
+    from scipy import ndimage as ndi
+    img2d = np.asarray(img2d)
+    if tuple(img2d.shape) == tuple(new_shape):
+        return img2d
+    zoom = [n / o for n, o in zip(new_shape, img2d.shape)]
+    out = ndi.zoom(img2d, zoom, order=order, mode='nearest', grid_mode=True)
+    if order > 0 and out.size:
+        np.clip(out, img2d.min(), img2d.max(), out=out)
+    return out.astype(img2d.dtype, copy=False)
+
+
+def resample_data_to_shape(data: np.ndarray, new_shape, order: int = 3) -> np.ndarray:
+    """``resample_data_or_seg_to_shape(data, new_shape, current_spacing, new_spacing, is_seg=False, order=3, order_z=0)`` for the
+    2-D configurations ts2d uses ([C, 1, H, W] with the 999 pseudo-spacing): upstream finds the 999 axis anisotropic and
+    resamples every (channel, slice) in-plane with ``resize``; the slice count does not change [UPSTREAM-RECALL]."""
+    new_shape = tuple(int(v) for v in new_shape)
+    if tuple(data.shape[1:]) == new_shape:
+        return data
+    if data.shape[1] != new_shape[0]:
+        raise NotImplementedError(f"resampling along the slice axis ({data.shape[1]} -> {new_shape[0]} slices) is not implemented (2-D configurations only)")
+    out = np.empty((data.shape[0],) + new_shape, dtype=data.dtype)
+    for c in range(data.shape[0]):
+        for z in range(data.shape[1]):
+            out[c, z] = resize_like_skimage(data[c, z], new_shape[1:], order)
+    return out
 
 
 def _device_zscore_applies(dz, data, bbox, tf, schemes, use_mask) -> bool:
@@ -108,7 +180,7 @@ class DefaultPreprocessor:
         data = data.transpose([0] + [i + 1 for i in tf])
         original_spacing = [properties['spacing'][i] for i in tf]
         properties['shape_before_cropping'] = data.shape[1:]
-        data, bbox = crop_to_nonzero(data)
+        data, bbox, nzmask = crop_to_nonzero(data, return_mask=True)
         properties['bbox_used_for_cropping'] = bbox
         properties['shape_after_cropping_and_before_resampling'] = data.shape[1:]
         target_spacing = list(configuration_manager.spacing)
@@ -120,21 +192,14 @@ class DefaultPreprocessor:
         dz = properties.pop('device_zscore', None)
         if dz is not None and not _device_zscore_applies(dz, data, bbox, tf, schemes, use_mask):
             dz = None
+        fip = (getattr(plans_manager, 'plans', None) or {}).get('foreground_intensity_properties_per_channel', {})
         for c in range(data.shape[0]):
             if dz is not None:          # normalised on the device behind the projection (ts2d_project_coronal_zscore): no host pass
                 data[c, 0] = dz['norm'][dz['order'][c]]
                 continue
-            if schemes[c] == 'ZScoreNormalization' and c < len(use_mask) and use_mask[c]:
-                # upstream then takes mean/std inside the nonzero mask only and leaves the outside at 0 - refuse rather than
-                # normalise differently in silence
-                raise NotImplementedError(f"use_mask_for_norm is set for channel {c}: masked ZScoreNormalization is not implemented")
-            if schemes[c] not in ('ZScoreNormalization', 'NoNormalization'):
-                raise NotImplementedError(f"normalization scheme {schemes[c]} is not implemented")
-            if schemes[c] == 'ZScoreNormalization':
-                data[c] = zscore(data[c])
-        if list(new_shape) != list(data.shape[1:]):
-            raise NotImplementedError(f"resampling {list(data.shape[1:])} -> {new_shape} (spacing {original_spacing} -> "
-                                      f"{target_spacing}) is not implemented")
+            data[c] = normalize_channel(data[c], schemes[c], bool(c < len(use_mask) and use_mask[c]), nzmask, fip.get(str(c)))
+        if list(new_shape) != list(data.shape[1:]):       # the plan's spacing differs from the image's: resample (order 3), AFTER normalising
+            data = resample_data_to_shape(data, new_shape, order=3)
         return data, None, properties
 
     def run_case(self, image_files: List[str], seg_file: Optional[str], plans_manager, configuration_manager, dataset_json):
