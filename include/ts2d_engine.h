@@ -125,7 +125,7 @@ int ts2d_engine_predict_tiled(ts2d_engine* e, const float* image, int Hp, int Wp
 
 /* Blend order of ts2d_engine_predict_tiled (upstream `prediction *= gaussian; predicted_logits[sl] += prediction` with
  * float16 `predicted_logits`; reached from ts2d/core/inference/prediction_worker.py:209):
- *   TS2D_TILE_F32 (default) the reference's CPU path (nnu.py:161-163 forces device=cpu, no autocast): the tile prediction is
+ *   TS2D_TILE_F32 (default) the reference's CPU path (nnu.py:161-163: device=cpu when torch.cuda.is_available() is false - no autocast): the tile prediction is
  *       fp32, the product is fp32 x float(half gaussian) in fp32, the sum is a float add with ONE rounding into the half buffer;
  *   TS2D_TILE_F16 the reference's CUDA path (fp16 autocast): the tile is half, the product and the sum each round to half. */
 #define TS2D_TILE_F32 0

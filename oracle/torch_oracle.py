@@ -4,8 +4,8 @@ PARITY PINNING: the reference pins no numerical result for this path (its tests 
 only: reference ``test/test_020_predict_default.py:37-38``, ``test/test_030_cli.py:14-15``) and the arithmetic
 lives in third-party wheels that are absent offline (``nnunetv2ml==2.6.2`` ``pyproject.toml:25`` ->
 ``dynamic_network_architectures`` -> ``torch``).  This file therefore restates the PUBLISHED upstream algorithm
-with the SAME ATen CPU kernels the reference dispatches to on its CPU path (``ts2d/core/inference/nnu.py:161-163``
-forces ``device=cpu``): ``F.conv2d``, ``F.instance_norm``, ``F.leaky_relu``, ``F.conv_transpose2d``, ``torch.cat``.
+with the SAME ATen CPU kernels the reference dispatches to on its CPU path (``ts2d/core/inference/nnu.py:161-163``:
+``device=cpu`` when ``torch.cuda.is_available()`` is false): ``F.conv2d``, ``F.instance_norm``, ``F.leaky_relu``, ``F.conv_transpose2d``, ``torch.cat``.
 Golden fixtures generated from it live in tests/golden/ (script tests/gen_golden.py).  Status: "parity pinned to the
 reference's arithmetic kernels, unpinned w.r.t. reference-produced vectors" (DESIGN.md section 3).
 
@@ -157,7 +157,7 @@ def predict_sliding_window(net, data: torch.Tensor, patch: Sequence[int], step: 
     Accumulators and the gaussian are float16 exactly as upstream (results_device = cpu).
 
     ``tile_dtype`` is the dtype the tile prediction ``p`` has when it meets the half buffers:
-      'float' (default) - the reference's CPU path (``nnu.py:161-163`` forces device=cpu, no autocast): ``network(x)`` is
+      'float' (default) - the reference's CPU path (``nnu.py:161-163``: device=cpu when ``torch.cuda.is_available()`` is false - no autocast): ``network(x)`` is
                 fp32, ``.to(results_device)`` moves device only, so ``p *= g`` is fp32 x half -> fp32 and
                 ``logits[sl] += p`` is ONE rounding into the half buffer (ATen computes half += float in float);
       'half'  - the CUDA path (fp16 autocast): ``p`` is half, so ``p * g`` and ``logits += p`` each round to half.

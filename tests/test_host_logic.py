@@ -166,3 +166,15 @@ def test_resampling_to_the_plan_spacing_and_back():
     assert np.array_equal(seg, (back > E.SIGMOID_HALF_THRESHOLD).astype(np.uint8))
     with pytest.raises(NotImplementedError):
         P.resample_data_to_shape(np.zeros((1, 2, 8, 8), np.float32), (4, 8, 8))               # slice axis: 3-D configurations only
+
+
+def test_blend_order_default_follows_the_precision_mode():
+    """the fp32-parity modes blend like the reference's CPU path (the one BASELINE.json compares with), the 16-bit mode
+    like its CUDA autocast path; an explicit tile_dtype wins."""
+    net = lambda x: np.zeros((x.shape[0], 2) + x.shape[2:], np.float32)
+    assert HIPnnUNetPredictor(network=net).tile_dtype == 'float'
+    assert HIPnnUNetPredictor(network=net, precision='exact').tile_dtype == 'float'
+    assert HIPnnUNetPredictor(network=net, precision='f16').tile_dtype == 'half'
+    assert HIPnnUNetPredictor(network=net, precision='f16', tile_dtype='float').tile_dtype == 'float'
+    with pytest.raises(ValueError):
+        HIPnnUNetPredictor(network=net, tile_dtype='double')

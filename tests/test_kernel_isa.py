@@ -1,0 +1,75 @@
+"""Build-time check of the one hand-counted wait in the kernels ("correctness of the LDS-DMA double buffering depends on
+the exact instruction stream hipcc emits"): conv3x3_upq waits with `s_waitcnt vmcnt(6)` for its weight DMA while the 6 patch loads
+of the chunk after next stay in flight across the barrier.  vmcnt counts vector-memory operations in issue order, so the wait is
+right iff exactly 6 VMEM operations (and no LDS-DMA) are issued between the last `global_load_lds` of the chunk and the wait.
+The kernels are compiled to assembly here (hipcc cross-compiles without a GPU) and the count is asserted; a compiler upgrade that
+duplicates, drops or reorders one of those loads fails this test instead of silently reading weights before they land."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests.conftest import ROOT
+
+HIPCC = '/opt/rocm/bin/hipcc'
+
+
+@pytest.fixture(scope='module')
+def asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip('hipcc not installed')
+    out = tmp_path_factory.mktemp('isa') / 'engine.s'
+    src = os.path.join(ROOT, 'totalsegmentator2d_amd', 'csrc', 'engine.hip')
+    subprocess.check_call([HIPCC, '-O3', '-std=c++17', '--offload-arch=gfx950', '--cuda-device-only', '-S', '-o', str(out), src],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _body(asm, mangled_fragment):
+    m = re.search(r'^(_ZN4ts2d\w*' + mangled_fragment + r'\w*):', asm, re.M)
+    assert m, f'kernel {mangled_fragment} not found in the assembly'
+    end = asm.index('.Lfunc_end', m.end())
+    return [ln.strip() for ln in asm[asm.index('\n', m.end()):end].split('\n') if ln.strip() and not ln.strip().startswith(';')]
+
+
+def _is_vmem(op):
+    return op.startswith(('buffer_', 'global_', 'scratch_', 'flat_'))
+
+
+def test_upq_counted_wait_matches_the_emitted_stream(asm):
+    body = _body(asm, 'conv3x3_upq')
+    waits = [i for i, ln in enumerate(body) if ln.startswith('s_waitcnt') and 'vmcnt(6)' in ln and body[i + 1].startswith('s_barrier')]
+    assert waits, 'the counted wait of conv3x3_upq (s_waitcnt vmcnt(6) directly in front of a barrier) is gone'
+    for wi in waits:
+        younger, j = 0, wi - 1
+        while j >= 0 and not body[j].startswith('global_load_lds'):
+            op = body[j].split()[0]
+            # (the only control flow here are the wave-uniform `if (a.prof)` skips of the diagnostic stamps: scalar code, no VMEM -
+            #  every vector-memory operation between the DMA and the wait is counted, whichever side of such a skip it is on)
+            if _is_vmem(op):
+                assert 'load' in op and 'lds' not in op, f'unexpected vector-memory operation behind the DMA: {body[j]}'
+                younger += 1
+            j -= 1
+        assert j >= 0, 'no LDS-DMA in front of the counted wait'
+        assert younger == 6, f'{younger} loads are issued behind the weight DMA, the wait counts 6'
+
+
+def test_persistent_pipelines_drain_before_their_barrier(asm):
+    """conv3x3_f16x3_qp / qp16 retire EVERYTHING (vmcnt(0)) in front of the per-item barrier: every barrier that follows a
+    global_load_lds in those kernels must be preceded by a vmcnt wait.  (conv3x3_upq leaves the loop with one surplus DMA of the
+    repeated last chunk in flight into a weight buffer nobody reads again: its epilogue barriers are LDS-only by design.)"""
+    for frag in ('conv3x3_f16x3_qpE', 'conv3x3_f16x3_qp16'):
+        body = _body(asm, frag)
+        pending = False
+        for i, ln in enumerate(body):
+            op = ln.split()[0]
+            if op.startswith('global_load_lds'):
+                pending = True
+            elif op == 's_waitcnt' and 'vmcnt' in ln:
+                pending = False
+            elif op == 's_barrier':
+                assert not pending, f'{frag}: a barrier is reached with an un-waited LDS-DMA in flight (line {i})'
+    # no register spills in the persistent kernels (a scratch reload is a VMEM operation: it would wait for the DMA, or be waited for)
+    for frag in ('conv3x3_f16x3_qpE', 'conv3x3_f16x3_qp16', 'conv3x3_upq'):
+        assert not any(ln.startswith('scratch_') for ln in _body(asm, frag)), f'{frag} spills registers'

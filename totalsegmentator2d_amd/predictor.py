@@ -51,10 +51,13 @@ class HIPnnUNetPredictor:
     def __init__(self, tile_step_size: float = 0.5, use_gaussian: bool = True, use_mirroring: bool = True,
                  perform_everything_on_device: bool = True, device=None, verbose: bool = False,
                  verbose_preprocessing: bool = False, allow_tqdm: bool = True, max_batch: int = 64, precision: str = 'split',
-                 tile_dtype: str = 'float', network: Optional[Callable[[np.ndarray], np.ndarray]] = None):
-        """``tile_dtype``: dtype of a tile prediction when it is blended into upstream's float16 buffers - 'float' (default;
-        the reference's CPU path: fp32 tile x half gaussian in fp32, ONE rounding per ``logits[sl] += p``) or 'half' (the CUDA
-        autocast path: the tile is half, the product and the sum each round to half).
+                 tile_dtype: Optional[str] = None, network: Optional[Callable[[np.ndarray], np.ndarray]] = None):
+        """``tile_dtype``: dtype of a tile prediction when it is blended into upstream's float16 buffers - 'float' (the
+        reference's CPU path, taken when ``torch.cuda.is_available()`` is false, ``nnu.py:161-163``: fp32 tile x half gaussian in
+        fp32, ONE rounding per ``logits[sl] += p``) or 'half' (the reference's CUDA path under fp16 autocast: the tile is half, the
+        product and the sum each round to half).  Default (None): the blend order of the reference path the chosen arithmetic
+        mirrors - 'float' for the fp32-parity modes ('split', 'exact': BASELINE.json compares with the CPU path), 'half' for
+        ``precision='f16'`` (the autocast-like mode).
         ``network``: test hook - a callable [B,C,h,w] -> [B,K,h,w] used INSTEAD of creating HIP engines (host-logic
         unit tests on machines without a GPU).  The product path never passes it."""
         self.tile_step_size = tile_step_size
@@ -68,8 +71,10 @@ class HIPnnUNetPredictor:
         if precision not in ('split', 'exact', 'f16'):
             raise ValueError("precision must be 'split' (fp32-equivalent, default), 'exact' (fp32 MFMA) or 'f16' (like the reference's CUDA autocast path)")
         self.precision = precision
+        if tile_dtype is None:
+            tile_dtype = 'half' if precision == 'f16' else 'float'
         if tile_dtype not in ('float', 'half'):
-            raise ValueError("tile_dtype must be 'float' (reference CPU path, default) or 'half' (CUDA autocast path)")
+            raise ValueError("tile_dtype must be 'float' (reference CPU path), 'half' (CUDA autocast path) or None (by precision)")
         self.tile_dtype = tile_dtype
         idx = 0
         if device is not None:
