@@ -54,14 +54,19 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
     const float* const sh1p = a.src1 ? a.sh1 : a.sh0;
 
     // ---- staging units: patch pixel pp = 32 (8 it + w) + (lane & 7) + 8 (lane >> 4) -> (py, px), tile-independent
-    int upk[MAXU], lw[MAXU];
+    //      (register budget: the kernel sits at the 256-register limit of two waves per SIMD - the three (py, px) pairs share ONE
+    //       register: px in 6 bits, py in 3 / 4 / 5 bits at bits 0 / 9 / 19, py >= 18 = the unit does not exist; the LDS write address of
+    //       unit it is lw0 + 4096 it.  Round 3: with the pivot of the shifted statistics two registers spilled INTO the loop.)
+    unsigned upk = 0;
 #pragma unroll
     for (int it = 0; it < MAXU; ++it) {
         const int pp = 32 * (8 * it + w) + (lane & 7) + 8 * (lane >> 4);
         const int py = pp / kPPW, px = pp - py * kPPW;
-        upk[it] = pp < kQSlots ? (py << 8) | px : -1;
-        lw[it] = octi * kQPlane + pp * 16;
+        upk |= (unsigned)((py << 6) | px) << (it == 0 ? 0 : (it == 1 ? 9 : 19));
     }
+    auto unit_py = [&](int it) { return (int)((upk >> (it == 0 ? 6 : (it == 1 ? 15 : 25))) & (it == 0 ? 7u : (it == 1 ? 15u : 31u))); };
+    auto unit_px = [&](int it) { return (int)((upk >> (it == 0 ? 0 : (it == 1 ? 9 : 19))) & 63u); };
+    const int lw0 = octi * kQPlane + (32 * w + (lane & 7) + 8 * (lane >> 4)) * 16;
     struct Item { int k, c; };                               // tile number within the workgroup, chunk
     auto advance = [&](Item& t) {                            // next item of the stream; the last item repeats (loaded / staged, never used)
         int c = t.c + 1, k = t.k;
@@ -77,7 +82,8 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
 
     u32x4 pv[MAXU][2];
     f32x4 nsa, nsb, nta, ntb;
-    unsigned real_pf = 0, real_cv = 0;                       // bit it: unit it of the prefetched / to-be-converted item lies inside the image
+    unsigned real_pf = 0;                                    // bit it: unit it of the prefetched item lies inside the image (read by convert, which
+                                                             // runs before the next prefetch overwrites it)
     auto prefetch = [&](const Item& t) {                     // 6 buffer loads + 4 global loads, branch-free
         int nimg, ty0, tx0, tin;
         tile_origin(t.k, nimg, ty0, tx0, tin);
@@ -89,8 +95,9 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
         unsigned m = 0;
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
-            const int iy = ty0 - 1 + (upk[it] >> 8), ix = tx0 - 1 + (upk[it] & 255);
-            const bool in = upk[it] >= 0 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            const int py = unit_py(it), px = unit_px(it);
+            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+            const bool in = (py < kQRows) & ((unsigned)iy < (unsigned)a.Hin) & ((unsigned)ix < (unsigned)a.Win);      // (bitwise: no short-circuit branches)
             const unsigned vo = in ? (unsigned)(((iy * a.Win + ix) * C + oct) * 4) : 0x80000000u;
             pv[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, cb * 4, 0);
             pv[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16, cb * 4, 0);
@@ -112,12 +119,12 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
         }
         uint4 hi, lo;
         split_hi_lo_8(va, vb, hi, lo);
-        const bool real = (real_cv >> it) & 1u;
+        const bool real = (real_pf >> it) & 1u;
         hi.x = real ? hi.x : 0u; hi.y = real ? hi.y : 0u; hi.z = real ? hi.z : 0u; hi.w = real ? hi.w : 0u;
         lo.x = real ? lo.x : 0u; lo.y = real ? lo.y : 0u; lo.z = real ? lo.z : 0u; lo.w = real ? lo.w : 0u;
-        if (it < 2 || upk[it] >= 0) {
-            *reinterpret_cast<uint4*>(pb + lw[it]) = hi;
-            *reinterpret_cast<uint4*>(pb + lw[it] + 2 * kQPlane) = lo;
+        if (it < 2 || unit_py(2) < kQRows) {
+            *reinterpret_cast<uint4*>(pb + lw0 + it * 4096) = hi;
+            *reinterpret_cast<uint4*>(pb + lw0 + it * 4096 + 2 * kQPlane) = lo;
         }
     };
     auto weights_dma = [&](int ch, unsigned char* wb) {     // 36 pieces of 1 KiB; every wave issues exactly 5 (pieces 32..35 twice)
@@ -131,7 +138,6 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
     // ---- fill the pipeline: item 0 staged synchronously (once per workgroup), item 1 requested
     Item cur{0, 0}, nx1{0, 0}, nx2{0, 0};
     prefetch(cur);
-    real_cv = real_pf;
     weights_dma(0, wbuf0);
 #pragma unroll
     for (int it = 0; it < MAXU; ++it) convert(it, smem8);
@@ -162,7 +168,6 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
         const unsigned char* pw = wbuf0 + b * kQWts + bbase;
         unsigned char* pb_next = smem8 + (b ^ 1) * kQPatch;
         unsigned char* wb_next = wbuf0 + (b ^ 1) * kQWts;
-        real_cv = real_pf;                                   // the registers hold item i+1 (requested one iteration ago)
 
         f32x16 acc_c[2][NT];
         half8 fa[2][2][2], fb[2][NT][2];                     // [buffer][tile][hi, lo]

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp16(const ConvArg
         for (int it = 0; it < MAXU; ++it) {
             const int py = unit_py(it), px = unit_px(it);
             const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-            const bool in = py < kQRows && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            const bool in = (py < kQRows) & ((unsigned)iy < (unsigned)a.Hin) & ((unsigned)ix < (unsigned)a.Win);      // (bitwise: no short-circuit branches)
             const unsigned vo = in ? (unsigned)(((iy * a.Win + ix) * C + oct) * 4) : 0x80000000u;
             pv[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, cb * 4, 0);
             pv[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16, cb * 4, 0);
