@@ -162,6 +162,7 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
     // SIMD loses every VALU arbitration to the older one); measured (gpurun r3, scripts/gpu_ab.py): 2.5-5 % per layer, off: TS2D_DBG=512
     if (!(a.dbg & 512)) { if (w >= 4) __builtin_amdgcn_s_setprio(1); }
     const int nitems = ntl * nchunks;
+    int pend = -1;                                           // statistics of a finished tile waiting for the item barrier: its entry in a.part
     for (int i = 0; i < nitems; ++i) {
         const int b = i & 1;
         const unsigned char* pa = smem8 + b * kQPatch + abase;
@@ -242,12 +243,16 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
                 s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
                 if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], 64.f);
             }
-            lds_barrier();
-            if (tid < BN) stat_tile_store(red, 8, BN, tid, a.part + ((size_t)(nimg * tpi + tin) * a.Cout + n0col + tid) * 4);
-            // (the next use of `red` is a whole tile away: the per-item barriers below order it)
+            // the cross-wave merge waits for the item's own barrier below instead of one of its own (in-kernel stamps of round 2: the
+            // extra barrier + its skew cost ~3 k cycles per tile); `red` is not written again before the next tile's epilogue
+            pend = (nimg * tpi + tin) * a.Cout + n0col;
         }
         advance(cur); advance(nx1); advance(nx2);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (pend >= 0) {                                     // (uniform)
+            if (tid < BN) stat_tile_store(reinterpret_cast<const float*>(smem8 + kQpRed), 8, BN, tid, a.part + ((size_t)pend + tid) * 4);
+            pend = -1;
+        }
     }
 }
 

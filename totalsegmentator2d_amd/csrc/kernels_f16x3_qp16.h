@@ -175,6 +175,7 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp16(const ConvArg
 
     if constexpr (VAR & 1) { if (w >= 4) __builtin_amdgcn_s_setprio(1); }
     const int nitems = ntl * nchunks;
+    int pend = -1;                                           // statistics of a finished tile waiting for the item barrier: its entry in a.part
     for (int i = 0; i < nitems; ++i) {
         const int b = i & 1;
         const unsigned char* pA = smem8 + b * kQ16Patch + xA;
@@ -342,12 +343,14 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp16(const ConvArg
 #pragma unroll
                 for (int pb = 0; pb < 4; ++pb) asm volatile("" :: "v"(ov[pb]));      // store data registers untouched up to here (dozens of VALU behind the stores)
             }
-            lds_barrier();
-            if (tid < BN) stat_tile_store(red, 8, BN, tid, a.part + ((size_t)(nimg * tpi + tin) * a.Cout + n0col + tid) * 4);
-            // (the next use of `red` is a whole tile away: the per-item barriers below order it)
+            pend = (nimg * tpi + tin) * a.Cout + n0col;      // the cross-wave merge waits for the item's own barrier below (kernels_f16x3_qp.h)
         }
         advance(cur); advance(nx1); advance(nx2);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (pend >= 0) {                                     // (uniform)
+            if (tid < BN) stat_tile_store(reinterpret_cast<const float*>(smem8 + kQ16Red), 8, BN, tid, a.part + ((size_t)pend + tid) * 4);
+            pend = -1;
+        }
     }
 }
 
