@@ -422,3 +422,25 @@ def test_activation_buffers_are_shared_by_liveness():
             e.keep_activations(True)
             b, mb = e.forward(x, logits=True, mask=True)
             assert np.array_equal(a, b) and np.array_equal(ma, mb), mode
+
+
+def test_opt_in_16x16x32_kernel_parity(monkeypatch):
+    """conv3x3_f16x3_qp16 (TS2D_Q16=1; kernels_f16x3_qp16.h): the persistent pipeline on v_mfma_f32_16x16x32_f16 with K packed by the
+    hi / lo parts.  Measured slower than the 32x32x16 form and therefore opt-in - but it is a complete kernel
+    and stays inside the fp32 parity tolerance, layer by layer and end to end; both experiment variants."""
+    from oracle import torch_oracle as O
+    arch, B, H, W, seed = cases.SMALL_CASES['net5_128']
+    sd, blob = blob_for(arch, seed)
+    x = cases.make_input(arch, B, H, W, seed)
+    ref, inter = O.unet_forward(arch, sd, x, return_intermediates=True)
+    monkeypatch.setenv('TS2D_Q16', '1')
+    for var in ('0', '1'):
+        monkeypatch.setenv('TS2D_Q16V', var)
+        with Engine(arch, blob) as e:
+            e.set_profiling(True)
+            lg, _ = e.forward(x)
+            kern = e.op_kernels()
+            assert kern['enc1.c1'] == 'conv3x3_f16x3_qp16' and kern['enc2.c1'] == 'conv3x3_f16x3_qp16'      # 64 ch @ 64x64, 128 ch @ 32x32
+            assert np.abs(lg - ref.numpy()).max() <= TOL
+            for n in ('enc1.c1', 'enc2.c1', 'dec1.c1'):
+                assert np.abs(e.debug_tensor(n) - inter[n].numpy()).max() <= TOL, n
