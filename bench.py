@@ -510,6 +510,27 @@ def main():
                 torch.cuda.synchronize(dev)
                 out['f16_mode'] = {'precision_mode': 'f16', 'value': round(B * max(2, args.steps // 2) / (time.perf_counter() - t1), 2), 'unit': 'slices/s',
                                    'note': 'fp16 storage + single fp16 MFMA product; logit rms error ~8e-3, outside the 1e-4 parity tolerance'}
+                if profile:
+                    # its own roofline block: the stride-1 3x3 family against the dense fp16 MFMA peak, and the whole step
+                    # against HBM on the layer-wise activation bytes of 2-byte storage (arch.work(act_bytes=2))
+                    engine.set_profiling(True)
+                    step(); torch.cuda.synchronize(dev)
+                    ot = engine.op_times()
+                    engine.set_profiling(False)
+                    hms = sum(v for k, v in ot.items() if k in per)
+                    htf = conv_flops / (hms * 1e-3) / 1e12
+                    w16 = arch.work(H, W, act_bytes=2)
+                    hv = out['f16_mode']['value']
+                    out['f16_mode']['roofline'] = {
+                        'bound': 'mfma', 'achieved': round(htf, 2), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(htf / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': None,
+                        'frac_of_measured_matrix_pipe_rate': round(htf / MEASURED_F16_PIPE_TFLOPS, 4),
+                        'kernel': f'conv3x3_h32 / conv3x3_h_qp16 / conv3x3_upc_h ({len(per)} stride-1 3x3 launches/step)',
+                        'kernel_ms_per_step': round(hms, 3), 'step_ms_profiled': round(sum(ot.values()), 3),
+                        'whole_step_tflops': round(hv * work['flops'] / 1e12, 1),
+                        'whole_step_hbm': {'bound': 'hbm', 'achieved': round(hv * w16['act_bytes'] / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                           'frac': round(hv * w16['act_bytes'] / 1e9 / PEAK_HBM_GBS, 4),
+                                           'act_mb_per_slice': round(w16['act_bytes'] / 1e6, 1)}}
             engine.set_precision(args.precision)
         if world == 1 and not args.no_cpu_baseline:
             step(); torch.cuda.synchronize(dev)

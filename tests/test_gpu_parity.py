@@ -290,6 +290,54 @@ def test_composed_upsampling_block_matches_the_two_kernel_path_and_the_oracle(mo
         assert np.abs(lg1 - ref).max() <= TOL and np.abs(lg0 - ref).max() <= TOL
 
 
+def test_level0_composed_block_runs_the_dedicated_kernel(monkeypatch):
+    """kernels_up0.h: the 64 -> (32 | 32) -> 32 decoder entry of the canonical level 0 as a persistent kernel (resident skip weights,
+    composed weights streamed in fragment order, 16x16x32 transposed product).  The kernel must be the one that serves dec0.c0 in
+    the split and the 16-bit mode; its output is checked against conv3x3_upc (TS2D_UP0=0), the two-kernel path (TS2D_UPC=0) and the
+    oracle on an extent with border tiles on all four sides, one tile per image column, and a segment that ends inside an image."""
+    from oracle import torch_oracle as O
+    from totalsegmentator2d_amd import weights
+    arch = cases.unet(3, (32, 64, 128), 5, cin=2)
+    for B, H, W, seed in ((3, 72, 96, 41), (2, 8, 32, 42), (1, 256, 512, 43)):      # 9 x 3 tiles, ONE tile (every border at once), 32 x 16 tiles
+        sd = weights.synthetic_state_dict(arch, seed)
+        for k in sd:
+            if 'transpconvs' in k and k.endswith('bias'):
+                sd[k] = (sd[k] * 40.0).astype(np.float32)      # a wrong bias variant at the border cannot hide
+        blob = weights.pack_blob(arch, sd)
+        x = cases.make_input(arch, B, H, W, seed)
+        ref = O.unet_forward(arch, sd, x).numpy()
+        out = {}
+        for tag, env in (('up0', {}), ('upc', {'TS2D_UP0': '0'}), ('two', {'TS2D_UPC': '0'})):
+            for k in ('TS2D_UP0', 'TS2D_UPC'):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            with Engine(arch, blob) as e:
+                e.set_profiling(True)
+                lg, _ = e.forward(x, logits=True)
+                kern = e.op_kernels()['dec0.c0']
+                e.set_profiling(False)
+                t = e.debug_tensor('dec0.c0')
+                lh = kh = None
+                if tag != 'two':                                # the 16-bit mode of the same two kernels
+                    e.set_precision('f16')
+                    e.set_profiling(True)
+                    lh, _ = e.forward(x, logits=True)
+                    kh = e.op_kernels()['dec0.c0']
+                    e.set_profiling(False)
+                out[tag] = (lg, t, kern, lh, kh)
+        pow2 = (W // 32) & (W // 32 - 1) == 0 and ((W // 32) * (H // 8)) & ((W // 32) * (H // 8) - 1) == 0
+        assert out['up0'][2] == 'conv3x3_up0' and out['up0'][4] == 'conv3x3_up0' and out['two'][2] != 'conv3x3_up0'
+        if pow2:                                                # (conv3x3_upc wants power-of-two tile counts; otherwise the generic kernel runs)
+            assert out['upc'][2] == 'conv3x3_upc<32>' and out['upc'][4] == 'conv3x3_upc_h<32>'
+        assert 'up0' not in out['upc'][2] and 'up0' not in out['upc'][4]
+        for tag in ('upc', 'two'):
+            assert np.abs(out['up0'][1] - out[tag][1]).max() <= 3e-5, (tag, H, W)
+        assert np.abs(out['up0'][0] - ref).max() <= TOL
+        d16 = out['up0'][3] - out['upc'][3]                     # two fp16 pipelines that differ in summation order only
+        assert np.abs(d16).max() <= 0.05 and np.sqrt(np.mean(d16 ** 2)) <= 5e-3, (float(np.abs(d16).max()), H, W)
+
+
 def test_randomised_shapes_against_the_torch_oracle():
     """A fixed-seed slice of scripts/gpu_fuzz_parity.py: random small architectures, channel counts, batch sizes and ragged
     extents (complete and partial pixel tiles, one- and multi-image tiles, power-of-two and other tilings), all three modes."""

@@ -82,3 +82,39 @@ def test_persistent_pipelines_drain_before_their_barrier(asm):
     assert len(loads) <= 4
     for i in loads:          # not between the item's DMA and its last MFMA
         assert not (dma and mfma and dma[-1] < i < mfma[-1]), 'conv3x3_f16x3_qp reloads a spilled register inside the MFMA stream'
+
+
+def test_up0_weight_ring_and_border_free_epilogue(asm):
+    """conv3x3_up0 (kernels_up0.h) depends on two properties of the emitted stream that a scheduler change can silently undo:
+      * the composed-weight ring: each k-step's four fragment loads must stay where they are issued (fenced, one k-step of MFMAs
+        ahead of their use).  Unfenced, hipcc sinks them next to their consumer - `load; s_waitcnt vmcnt(0); mfma`, one L2 round
+        trip in front of every k-step (measured: 10 000 instead of 6 000 cycles for the phase);
+      * the interior copy of the epilogue stores its 8 vectors with NO vmcnt wait in between (one shared copy puts the wait for the
+        border tiles' bias-variant loads - vmcnt(0): the next tile's patches in flight - in front of every store of every tile).
+    Also: no register spill inside the two MFMA phases (a scratch reload is a VMEM operation behind the prefetch)."""
+    body = _body(asm, 'conv3x3_up0IfLi3E')
+    bars = [i for i, ln in enumerate(body) if ln.split()[0] == 's_barrier']
+    assert len(bars) >= 4
+    # phase B = between the tile loop's first and second barrier (the last 4 barriers of the function belong to the loop)
+    b0, b1, b2, b3 = bars[-4], bars[-3], bars[-2], bars[-1]
+    phase_b = body[b0:b1]
+    assert sum('v_mfma' in ln for ln in phase_b) == 192
+    loads = [i for i, ln in enumerate(phase_b) if ln.startswith('buffer_load_dwordx4')]
+    assert len(loads) == 24, len(loads)                      # 6 k-steps x 4 fragments reloaded inside the phase (2 k-steps come from phase A)
+    for i in loads:
+        nxt = [ln for ln in phase_b[i + 1:i + 4] if not ln.startswith('buffer_load')]
+        assert not any(ln.startswith('s_waitcnt') and 'vmcnt(0)' in ln for ln in nxt), 'a ring load is waited for right where it is issued'
+    groups = sum(1 for k, i in enumerate(loads) if k == 0 or i != loads[k - 1] + 1)
+    assert groups <= 12                                       # issued as (about) one block per k-step (hazard nops may split one), not scattered to their consumers
+    for seg in (body[b0:b1], body[b2:b3]):
+        mf = [i for i, ln in enumerate(seg) if 'v_mfma' in ln]
+        assert not any(ln.startswith('scratch_') for ln in seg[mf[0]:mf[-1]]), 'spill reload inside an MFMA phase'
+    # interior epilogue: a run of 8 wide stores with no vmcnt wait inside
+    tail = body[b2:]
+    st = [i for i, ln in enumerate(tail) if ln.startswith('buffer_store_dwordx4')]
+    assert len(st) == 16                                      # two copies (border / interior)
+    clean = 0
+    for run in (st[:8], st[8:]):
+        inner = tail[run[0]:run[-1]]
+        clean += not any(ln.startswith('s_waitcnt') and 'vmcnt' in ln for ln in inner)
+    assert clean >= 1, 'no copy of the epilogue stores its tile without waiting on memory'

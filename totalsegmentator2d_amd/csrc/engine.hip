@@ -15,6 +15,7 @@
 #include "kernels_res32.h"
 #include "kernels_s2v2.h"
 #include "kernels_upc.h"
+#include "kernels_up0.h"
 #include "kernels_upq.h"
 #include "kernels_upc_h.h"
 #include "kernels_sw.h"
@@ -89,6 +90,9 @@ struct Op {
     size_t dev_wk = 0;            // skip half of the 3x3 weights [chunk Cs/16][column tile][tap][hi,lo][h][column][8 halves]
     size_t dev_wcs = 0;           // 1 / (their common power-of-two pre-scale)
     size_t dev_bvar = 0;          // [9 = (ry, rx)][Cout] bias variants
+    bool up0_ok = false;          // ... with 64 coarse, 32 skip and 32 output channels (level 0 of the canonical net): kernels_up0.h
+    size_t dev_w0c = 0;           // composed weights in fragment order [parity 4][k-step 8][hi,lo][cb 2][lane 64][8 halves]
+    size_t dev_w0k = 0;           // skip half, resident image [tap 9][hi,lo][g 4][cout 32][8 halves]
     bool first_direct = false;    // first conv block handled by conv3x3_first (reads the NCHW boundary tensor)
     size_t dev_wraw = 0;
 };
@@ -134,6 +138,7 @@ struct ts2d_engine {
     bool use_q = true;            // persistent 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (TS2D_Q=0 falls back to conv3x3_f16x3_one)
     int q16_var = 0;              // TS2D_Q16V: experiment switches of conv3x3_f16x3_qp16
     bool use_q16 = false;         // TS2D_Q16=1: ... on v_mfma_f32_16x16x32_f16 (conv3x3_f16x3_qp16: measured 1.5-10 % slower than the 32x32x16 form, opt-in)
+    bool use_up0 = true;          // dedicated persistent kernel of the level-0 composed block (TS2D_UP0=0: conv3x3_upc<32>)
     bool use_upq = true;          // 512-thread double-buffered variant of the composed block on 16 x 32 tiles (TS2D_UPQ=0: conv3x3_upc)
     bool use_upc = true;          // decoder c0 blocks composed with their transposed conv (TS2D_UPC=0 falls back to two kernels)
     unsigned long long* d_prof = nullptr;     // TS2D_DBG=256: in-kernel phase counters, 8 per op (diagnostic)
@@ -270,6 +275,11 @@ int build_program(ts2d_engine* e) {
                 op.dev_wk = wo; wo = align_up(wo + (size_t)op.cin_skip * op.cout * 9, 64);
                 op.dev_wcs = wo; wo = align_up(wo + 1, 64);
                 op.dev_bvar = wo; wo = align_up(wo + (size_t)9 * op.cout, 64);
+                if (cb == 64 && op.cin == 32 && op.cin_skip == 32 && op.cout == 32) {
+                    op.up0_ok = true;
+                    op.dev_w0c = wo; wo = align_up(wo + 4 * 8 * 2 * 2 * 64 * 8 / 2, 64);
+                    op.dev_w0k = wo; wo = align_up(wo + 9 * 2 * 4 * 32 * 8 / 2, 64);
+                }
             }
             if (op.stride == 1 && op.cin % 32 == 0 && op.cin_skip % 32 == 0) {      // [chunk32][column tile][tap][column][32 halves]
                 op.h32_ok = true;
@@ -484,6 +494,13 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                     const int hh = (cb % 16) / 8;
                     dc[((base + 0 + hh) * bn + co % bn) * 8 + cb % 8] = hi;
                     dc[((base + 2 + hh) * bn + co % bn) * 8 + cb % 8] = lo;
+                    if (op.up0_ok) {       // fragment order of conv3x3_up0: lane = k-group (cb % 32) / 8, row co % 16
+                        uint16_t* d0 = reinterpret_cast<uint16_t*>(out + op.dev_w0c);
+                        const size_t f = ((size_t)(t >> 2) * 8 + (cb / 32) * 4 + (t & 3)) * 4;      // (parity, k-step) x [hi,lo][cb 2]
+                        const int ln = ((cb % 32) / 8) * 16 + co % 16;
+                        d0[((f + 0 + co / 16) * 64 + ln) * 8 + cb % 8] = hi;
+                        d0[((f + 2 + co / 16) * 64 + ln) * 8 + cb % 8] = lo;
+                    }
                 }
             for (int cs = 0; cs < cs_n; ++cs)
                 for (int tap = 0; tap < 9; ++tap) {
@@ -493,6 +510,11 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                     const int hh = (cs % 16) / 8;
                     dk[((base + 0 + hh) * bn + co % bn) * 8 + cs % 8] = hi;
                     dk[((base + 2 + hh) * bn + co % bn) * 8 + cs % 8] = lo;
+                    if (op.up0_ok) {
+                        uint16_t* k0 = reinterpret_cast<uint16_t*>(out + op.dev_w0k);
+                        k0[((((size_t)tap * 2 + 0) * 4 + cs / 8) * 32 + co) * 8 + cs % 8] = hi;
+                        k0[((((size_t)tap * 2 + 1) * 4 + cs / 8) * 32 + co) * 8 + cs % 8] = lo;
+                    }
                 }
         });
         // bias variants: the transposed conv's bias reaches an output pixel through the taps that lie inside the image
@@ -896,12 +918,19 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
 
 // Does the decoder block `op` (3x3 conv over cat(up, skip)) run as ONE kernel together with its transposed conv for this geometry?
 // (the activation plan of ensure_workspace relies on the SAME answer at run time: it depends on (precision, H, W) only)
+// ... and as the dedicated level-0 kernel (kernels_up0.h)?  Ht x Wt: the block's output extent (complete 8 x 32 tiles).
+bool up0_applies(const ts2d_engine* e, const Op& op, int Ht, int Wt) {
+    return op.up0_ok && e->use_up0 && Ht % 8 == 0 && Wt % 32 == 0 && (size_t)Ht * Wt * 32 * 4 < ((size_t)1 << 31) &&
+           e->tensors[e->ops[op.up_idx].src].scale != nullptr && e->tensors[op.skip].scale != nullptr;
+}
+
 bool upc_applies(const ts2d_engine* e, const Op& op, int B, int H, int W) {
     if (!op.upc_ok || !e->use_upc || !e->use_one || e->precision == TS2D_PRECISION_F32_EXACT) return false;
     if (e->precision == TS2D_PRECISION_F16 && (op.cin_skip % 32 || e->tensors[e->ops[op.up_idx].src].scale == nullptr || e->tensors[op.skip].scale == nullptr))
         return false;                       // (the 16-bit kernel walks the skip channels in chunks of 32 and normalises both sources)
     const int Ht = H >> op.level, Wt = W >> op.level;
     if (Ht % 8 || Wt % 32) return false;
+    if (up0_applies(e, op, Ht, Wt)) return B > 0;       // (walks its tiles by division: any tile count)
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
     const int bn = op.cout % 64 == 0 ? 64 : 32;
     if (!pow2(Wt / 32) || !pow2((Wt / 32) * (Ht / 8)) || !pow2(op.cout / bn)) return false;
@@ -996,7 +1025,30 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const bool upq = !f16 && e->use_upq && bn == 64 && up.cin >= 256 && Ht % 16 == 0 &&      // (Cb = 128: no faster than conv3x3_upc, measured)
                              pow2(Wt / 32) && pow2((Wt / 32) * (Ht / 16)) && xc.scale != nullptr &&
                              sk.scale != nullptr && up.cin <= 512 && op.cin_skip <= 512;
-            if (f16) {       // 16-bit mode: fp16 storage, one product (kernels_upc_h.h)
+            const bool up0 = up0_applies(e, op, Ht, Wt);
+            if (up0) {       // level 0: persistent, resident skip weights, 16x16x32 transposed product (kernels_up0.h)
+                Up0Args u0{};
+                u0.xc = xc.data; u0.scc = xc.scale; u0.shc = xc.shift; u0.xs = sk.data; u0.scs = sk.scale; u0.shs = sk.shift;
+                u0.wc0 = wts + op.dev_w0c; u0.wk0 = wts + op.dev_w0k; u0.bvar = wts + op.dev_bvar; u0.oscale = wts + op.dev_wcs;
+                u0.dst = dst.data; u0.part = e->d_part;
+                u0.B = B; u0.H = Ht; u0.W = Wt; u0.tiles_x = Wt / 32; u0.tiles_y = Ht / 8; u0.n_tiles = B * u0.tiles_x * u0.tiles_y;
+                u0.slope = a.leaky_slope;
+                u0.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
+                const int tpi0 = u0.tiles_x * u0.tiles_y, want = std::min(u0.n_tiles, 2 * e->num_cus);
+                int seg = 1;          // (segments as conv3x3_res32: the largest divisor of an image's tiles that leaves >= 2 workgroups per CU)
+                for (int d = 1; d <= tpi0; ++d) if (tpi0 % d == 0 && u0.n_tiles / d >= want) seg = d;
+                u0.seg = seg;
+                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_up0");
+                if (f16) {
+                    static std::atomic<uint64_t> done0h{0};
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_up0<_Float16, 1>), done0h));
+                    hipLaunchKernelGGL((conv3x3_up0<_Float16, 1>), dim3(u0.n_tiles / seg), dim3(kBlock), 9 * 4 * 512 + 4 * kResPS + 1536, st, u0);
+                } else {
+                    static std::atomic<uint64_t> done0{0};
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_up0<float, 3>), done0));
+                    hipLaunchKernelGGL((conv3x3_up0<float, 3>), dim3(u0.n_tiles / seg), dim3(kBlock), 9 * 2 * 4 * 512 + 8 * kResPS, st, u0);
+                }
+            } else if (f16) {       // 16-bit mode: fp16 storage, one product (kernels_upc_h.h)
                 const int ks = up.cin % 64 == 0 ? 4 : 2;
                 const size_t smem_h = std::max((size_t)ks * 2 * kUcPlane, (size_t)4 * kUsPlane + (size_t)2 * 9 * 2 * bn * 16);
                 TRY(prof_begin(e, op.name, st)); prof_kernel(e, bn == 64 ? "conv3x3_upc_h<64>" : "conv3x3_upc_h<32>");
@@ -1302,6 +1354,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_Q16")) e->use_q16 = getenv("TS2D_Q16")[0] == '1';
         if (getenv("TS2D_Q16V")) e->q16_var = atoi(getenv("TS2D_Q16V"));
         if (getenv("TS2D_UPQ")) e->use_upq = getenv("TS2D_UPQ")[0] == '1';
+        if (getenv("TS2D_UP0")) e->use_up0 = getenv("TS2D_UP0")[0] == '1';
         if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
     }
