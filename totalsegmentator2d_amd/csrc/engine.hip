@@ -136,6 +136,7 @@ struct ts2d_engine {
     int dbg = 0;                  // TS2D_DBG: timing ablations (diagnostic runs only)
     bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
     bool use_q = true;            // persistent 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (TS2D_Q=0 falls back to conv3x3_f16x3_one)
+    int upq_min = 256;            // TS2D_UPQ_MIN: least coarse channel count served by conv3x3_upq
     int q16_var = 0;              // TS2D_Q16V: experiment switches of conv3x3_f16x3_qp16
     bool use_q16 = false;         // TS2D_Q16=1: ... on v_mfma_f32_16x16x32_f16 (conv3x3_f16x3_qp16: measured 1.5-10 % slower than the 32x32x16 form, opt-in)
     bool use_up0 = true;          // dedicated persistent kernel of the level-0 composed block (TS2D_UP0=0: conv3x3_upc<32>)
@@ -1022,7 +1023,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const int grid = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
             const size_t smem_u = std::max((size_t)8 * kUcPlane, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
             auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-            const bool upq = !f16 && e->use_upq && bn == 64 && up.cin >= 256 && Ht % 16 == 0 &&      // (Cb = 128: no faster than conv3x3_upc, measured)
+            const bool upq = !f16 && e->use_upq && bn == 64 && up.cin >= e->upq_min && Ht % 16 == 0 &&      // (Cb = 128: no faster than conv3x3_upc, measured)
                              pow2(Wt / 32) && pow2((Wt / 32) * (Ht / 16)) && xc.scale != nullptr &&
                              sk.scale != nullptr && up.cin <= 512 && op.cin_skip <= 512;
             const bool up0 = up0_applies(e, op, Ht, Wt);
@@ -1353,6 +1354,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_Q")) e->use_q = getenv("TS2D_Q")[0] == '1';
         if (getenv("TS2D_Q16")) e->use_q16 = getenv("TS2D_Q16")[0] == '1';
         if (getenv("TS2D_Q16V")) e->q16_var = atoi(getenv("TS2D_Q16V"));
+        if (getenv("TS2D_UPQ_MIN")) e->upq_min = atoi(getenv("TS2D_UPQ_MIN"));
         if (getenv("TS2D_UPQ")) e->use_upq = getenv("TS2D_UPQ")[0] == '1';
         if (getenv("TS2D_UP0")) e->use_up0 = getenv("TS2D_UP0")[0] == '1';
         if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';

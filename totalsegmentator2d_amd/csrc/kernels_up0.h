@@ -38,6 +38,8 @@ struct Up0Args {
 };
 
 constexpr int kU0CP = 1792;        // coarse plane: 108 slots (+ 4)
+constexpr int kU0NT = 0;            // cache policy of the output stores.  nt (2) measured: stores 2.07 -> 2.12 ms (16-bit mode, 8-byte stores: 1.04 -> 1.28: partial
+                                    // lines no longer merge in L2); nt on the patch loads as well: 2.24 / 1.35 ms (the halo re-reads of the neighbour tiles miss)
 constexpr bool kU0Burst = false;     // all 20 prefetch loads at the first tap (measured equal: the CU memory path is the bound either way; more spills)
 constexpr int kU0Ring = 2;         // k-steps of composed weights in flight per wave
 
@@ -361,14 +363,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
                     // wide-store hazard of gfx950 (kernels_res32.h: a VALU write to the data registers right behind a 128-bit store reaches
                     // the stored data): the offset rides in the VGPR and wait states follow the store
                     if constexpr (sizeof(ST) == 4) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsd, vst + soff, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsd, vst + soff, 0, kU0NT);
                     } else {
                         typedef _Float16 half4 __attribute__((ext_vector_type(4)));
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                         half4 hv;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) { hv[i] = (_Float16)v[i]; v[i] = (float)hv[i]; }
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rsd, vst + soff, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rsd, vst + soff, 0, kU0NT);
                     }
                     asm volatile("s_nop 3" ::: "memory");
 #pragma unroll
