@@ -407,15 +407,16 @@ def main():
             peak = {'split': PEAK_F16_MFMA_TFLOPS / 3.0, 'exact': PEAK_FP32_MFMA_TFLOPS, 'f16': PEAK_F16_MFMA_TFLOPS}[args.precision]
             # (b) the DOMINANT KERNEL, chosen by measured time: ops grouped by the kernel that served them (ts2d_engine_op_kernel).
             #     Algorithmic FLOPs of an op = the reference's own arithmetic (2 x MACs of the conv; a composed block
-            #     conv3x3_upc also carries the MACs of the ConvTranspose2d it absorbed, whose own launch no longer exists).
+            #     conv3x3_upc / _upq / _up0 also carries the MACs of the ConvTranspose2d it absorbed, whose own launch no longer exists).
             alg = {n: 2.0 * m['macs'] for n, (o, m) in layer.items()}
+            COMPOSED = ('conv3x3_upc', 'conv3x3_upq', 'conv3x3_up0')     # kernels that absorbed the ConvTranspose2d in front of them
             groups = {}
             for n, kname in op_kernels.items():
                 if n.endswith('.stats') or n not in ms or n not in alg:
                     continue
                 g = groups.setdefault(kname, {'ops': [], 'ms': 0.0, 'flops': 0.0})
                 g['ops'].append(n); g['ms'] += ms[n]; g['flops'] += alg[n] * B
-                if kname.startswith('conv3x3_upc'):
+                if kname.startswith(COMPOSED):
                     g['flops'] += alg.get(n.replace('.c0', '.up'), 0.0) * B
             pmc_avg, traffic_stale = {}, None
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -423,7 +424,7 @@ def main():
                 try:
                     pj = json.load(open(pmc))
                     traffic_stale = pj.get('csrc_hash') != csrc_hash()          # measured on other kernel sources: do not report it
-                    pmc_avg = {} if traffic_stale else pj.get('hbm_bytes_per_launch_avg', {})
+                    pmc_avg = {} if (traffic_stale or args.precision != 'split') else pj.get('hbm_bytes_per_launch_avg', {})      # (counters were collected in split mode)
                 except Exception:
                     pmc_avg = {}
             pipe = MEASURED_F16_PIPE_TFLOPS / (3.0 if split else 1.0)
@@ -462,7 +463,7 @@ def main():
                     cin = o['cin'] + o.get('cin_skip', 0)
                     px_in = (H * W) if o['op'] != 1 else (H * W) // 4          # transposed conv reads the level below
                     rd = px_in * cin * (4 if o['src'] == 'input' else esz)
-                    if op_kernels.get(n, '').startswith('conv3x3_upc'):      # composed block: reads the COARSE tensor instead of `up`
+                    if op_kernels.get(n, '').startswith(COMPOSED):           # composed block: reads the COARSE tensor instead of `up`
                         rd = ((H * W) // 4 * layer[n.replace('.c0', '.up')][0]['cin'] + H * W * o['cin_skip']) * esz
                     wr = H * W * o['cout'] * (4 if n == 'head' else esz)
                     l0[n] = (rd + wr) * B
@@ -525,7 +526,7 @@ def main():
                         'bound': 'mfma', 'achieved': round(htf, 2), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(htf / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': None,
                         'frac_of_measured_matrix_pipe_rate': round(htf / MEASURED_F16_PIPE_TFLOPS, 4),
-                        'kernel': f'conv3x3_h32 / conv3x3_h_qp16 / conv3x3_upc_h ({len(per)} stride-1 3x3 launches/step)',
+                        'kernel': f'conv3x3_h32 / conv3x3_h_qp16 / conv3x3_upc_h / conv3x3_up0 / conv3x3_res32 ({len(per)} stride-1 3x3 launches/step)',
                         'kernel_ms_per_step': round(hms, 3), 'step_ms_profiled': round(sum(ot.values()), 3),
                         'whole_step_tflops': round(hv * work['flops'] / 1e12, 1),
                         'whole_step_hbm': {'bound': 'hbm', 'achieved': round(hv * w16['act_bytes'] / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
