@@ -40,6 +40,8 @@ struct Up0Args {
 constexpr int kU0CP = 1792;        // coarse plane: 108 slots (+ 4)
 constexpr int kU0NT = 0;            // cache policy of the output stores.  nt (2) measured: stores 2.07 -> 2.12 ms (16-bit mode, 8-byte stores: 1.04 -> 1.28: partial
                                     // lines no longer merge in L2); nt on the patch loads as well: 2.24 / 1.35 ms (the halo re-reads of the neighbour tiles miss)
+constexpr bool kU0Rot = false;       // k-step order rotated per tile, so that the workgroups do not all walk the same 4 KB of the weight image at once: measured
+                                    // SLOWER (2.08 -> 2.21 ms, 16-bit mode 1.04 -> 1.14): same-address traffic is what the L2 serves best
 constexpr bool kU0Burst = false;     // all 20 prefetch loads at the first tap (measured equal: the CU memory path is the bound either way; more spills)
 constexpr int kU0Ring = 2;         // k-steps of composed weights in flight per wave
 
@@ -191,8 +193,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
         const unsigned edge = (tyi == 0 ? 1u : 0u) | (tyi == a.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) | (txi == a.tiles_x - 1 ? 8u : 0u);
         // ============================================================ A: coarse patch -> LDS (norm + LeakyReLU + split on the fly)
         __builtin_amdgcn_sched_barrier(0);
-        #pragma unroll
-        for (int s = 0; s < kU0Ring; ++s) wload(s, s);                        // the first two k-steps' weights (behind the previous tile's stores in the vmcnt order)
+                // (experiment switch kU0Rot: k-step order rotated by the tile's index inside its image)
+        const int rot = kU0Rot ? ((t - n * tpi) & 7) : 0;
+#pragma unroll
+        for (int s = 0; s < kU0Ring; ++s) wload(s, (s + rot) & 7);                        // the first two k-steps' weights (behind the previous tile's stores in the vmcnt order)
         {
             f32x4 csa, csb, cta, ctb;
             gather8(nsc, 8 * cg, csa, csb); gather8(ntc, 8 * cg, cta, ctb);
@@ -223,13 +227,15 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int ks = s >> 2, dI = (s >> 1) & 1, dJ = s & 1;
+            const int sr = (s + rot) & 7;                  // the k-step this iteration computes (rot = 0: s)
+            const int koff = (sr >> 2) * WIN + (((sr >> 1) & 1) * 18 + (sr & 1)) * 16;      // (scalar) half ks, tap (dI, dJ)
+            const unsigned char* xa = smem8 + cbase + koff;
             half8 fx[4][NPP];
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb)
 #pragma unroll
                 for (int pt2 = 0; pt2 < NPP; ++pt2)
-                    fx[pb][pt2] = *reinterpret_cast<const half8*>(smem8 + cbase + (pt2 * 2 + ks) * WIN + ((pb + dI) * 18 + dJ) * 16);
+                    fx[pb][pt2] = *reinterpret_cast<const half8*>(xa + pt2 * 2 * WIN + pb * 18 * 16);
             if constexpr (NP == 3) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
                 for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[s % kU0Ring][0][cb], fx[pb][0], acc[cb][pb], 0, 0, 0);
             if (s + kU0Ring < 8) {                                // (fenced: the scheduler otherwise sinks the loads next to their use two k-steps
                 __builtin_amdgcn_sched_barrier(0);          //  later - a full L2 round trip per fragment in front of its MFMAs)
-                wload(s % kU0Ring, s + kU0Ring);
+                wload(s % kU0Ring, (s + kU0Ring + rot) & 7);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
