@@ -19,6 +19,12 @@ for t in range(n):
         for i in range(1, ns): feats.append(min(feats[-1] * 2, 256))
         K = int(rng.integers(1, 27)); cin = int(rng.integers(1, 3))
         H = 64 * int(rng.integers(1, 5)); W = 128 * int(rng.integers(1, 4)); B = int(rng.integers(1, 4))
+        if t % 3 == 2:                                   # any tile count (conv3x3_up0 walks tiles by division; the other composed kernels want powers of two)
+            H = 8 * (1 << (ns - 1)) // 8 * int(rng.integers(1, 12)) if ns > 3 else 8 * int(rng.integers(1, 30)) // 4 * 4
+            H = max(H, 1 << (ns - 1)) // (1 << (ns - 1)) * (1 << (ns - 1))
+            W = 32 * int(rng.integers(1, 13))
+            W = max(W, 32) // (1 << (ns - 1)) * (1 << (ns - 1))
+            if H == 0 or W == 0: H, W = 64, 128
         arch = cases.unet(ns, feats, K, cin=cin, nconv=int(rng.integers(1, 3)))
         sd = weights.synthetic_state_dict(arch, 500 + t); blob = weights.pack_blob(arch, sd)
         x = prng.normal_f32(600 + t, 1, (B, cin, H, W))

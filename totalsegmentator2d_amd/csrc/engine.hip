@@ -922,12 +922,14 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
 // ... and as the dedicated level-0 kernel (kernels_up0.h)?  Ht x Wt: the block's output extent (complete 8 x 32 tiles).
 bool up0_applies(const ts2d_engine* e, const Op& op, int Ht, int Wt) {
     return op.up0_ok && e->use_up0 && Ht % 8 == 0 && Wt % 32 == 0 && (size_t)Ht * Wt * 32 * 4 < ((size_t)1 << 31) &&
-           e->tensors[e->ops[op.up_idx].src].scale != nullptr && e->tensors[op.skip].scale != nullptr;
+           e->tensors[e->ops[op.up_idx].src].normed && e->tensors[op.skip].normed;       // (`normed`, not the scale POINTERS: the activation
+           // plan asks this question before the workspace - and with it the pointers - exists; a plan made for the two-kernel path and
+           // a run that composes would place the block's output on a buffer the run still reads)
 }
 
 bool upc_applies(const ts2d_engine* e, const Op& op, int B, int H, int W) {
     if (!op.upc_ok || !e->use_upc || !e->use_one || e->precision == TS2D_PRECISION_F32_EXACT) return false;
-    if (e->precision == TS2D_PRECISION_F16 && (op.cin_skip % 32 || e->tensors[e->ops[op.up_idx].src].scale == nullptr || e->tensors[op.skip].scale == nullptr))
+    if (e->precision == TS2D_PRECISION_F16 && (op.cin_skip % 32 || !e->tensors[e->ops[op.up_idx].src].normed || !e->tensors[op.skip].normed))
         return false;                       // (the 16-bit kernel walks the skip channels in chunks of 32 and normalises both sources)
     const int Ht = H >> op.level, Wt = W >> op.level;
     if (Ht % 8 || Wt % 32) return false;
@@ -1038,6 +1040,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 const int tpi0 = u0.tiles_x * u0.tiles_y, want = std::min(u0.n_tiles, 2 * e->num_cus);
                 int seg = 1;          // (segments as conv3x3_res32: the largest divisor of an image's tiles that leaves >= 2 workgroups per CU)
                 for (int d = 1; d <= tpi0; ++d) if (tpi0 % d == 0 && u0.n_tiles / d >= want) seg = d;
+                if (getenv("TS2D_U0SEG") && atoi(getenv("TS2D_U0SEG")) > 0 && tpi0 % atoi(getenv("TS2D_U0SEG")) == 0) seg = atoi(getenv("TS2D_U0SEG"));      // (test switch)
                 u0.seg = seg;
                 TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_up0");
                 if (f16) {
