@@ -118,3 +118,23 @@ def test_up0_weight_ring_and_border_free_epilogue(asm):
         inner = tail[run[0]:run[-1]]
         clean += not any(ln.startswith('s_waitcnt') and 'vmcnt' in ln for ln in inner)
     assert clean >= 1, 'no copy of the epilogue stores its tile without waiting on memory'
+
+
+def test_weight_rings_keep_their_lookahead(asm):
+    """The composed decoder kernels read their B operand straight from L2 through a register ring that is reloaded a few taps ahead
+    of its use.  hipcc's scheduler sinks such reloads down to their consumers unless they are fenced (`sched_barrier`): the
+    emitted stream then shows `load ... s_waitcnt vmcnt(0..3) ... mfma` in the middle of an MFMA run - an L2 round trip in front of
+    every tap (found with conv3x3_up0; conv3x3_upc<64> ran 5 % slower that way).  Assert that no such tight wait sits between two
+    MFMAs right behind a plain global load in the kernels that carry a ring."""
+    for frag in ('conv3x3_up0IfLi3E', 'conv3x3_upcILi64E', 'conv3x3_upqE', 'conv3x3_upc_hILi64ELi4E'):
+        body = _body(asm, frag)
+        tight = 0
+        for i, ln in enumerate(body):
+            m = re.search(r'vmcnt\((\d+)\)', ln) if ln.startswith('s_waitcnt') else None
+            if not m or int(m.group(1)) > 3:
+                continue
+            before = any('v_mfma' in x for x in body[max(0, i - 4):i])
+            after = any('v_mfma' in x for x in body[i + 1:i + 4])
+            recent = any(x.startswith(('buffer_load', 'global_load')) and 'lds' not in x for x in body[max(0, i - 12):i])
+            tight += before and after and recent
+        assert tight == 0, f'{frag}: {tight} ring loads are waited for right where they are issued'

@@ -43,13 +43,13 @@ constexpr int kU0NT = 0;            // cache policy of the output stores.  nt (2
 constexpr bool kU0Rot = false;       // k-step order rotated per tile, so that the workgroups do not all walk the same 4 KB of the weight image at once: measured
                                     // SLOWER (2.08 -> 2.21 ms, 16-bit mode 1.04 -> 1.14): same-address traffic is what the L2 serves best
 constexpr bool kU0Burst = false;     // all 20 prefetch loads at the first tap (measured equal: the CU memory path is the bound either way; more spills)
-constexpr int kU0Ring = 2;         // k-steps of composed weights in flight per wave
 
 template <typename ST, int NP>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
     constexpr int NPP = NP == 3 ? 2 : 1;
     constexpr int WB = 9 * NPP * 4 * 512;                  // resident skip weights (bytes)
     constexpr int NL = sizeof(ST) == 4 ? 2 : 1;            // 16-byte loads per staging unit (8 channels)
+    constexpr int RING = NP == 3 ? 2 : 8;                  // k-steps of composed weights in flight per wave (16-bit mode: a k-step is 8 MFMAs - all eight requested up front)
     constexpr int NUS = 6, NUC = 4;                        // staging units per thread: skip 6 x 64 >= 340 pixels, coarse 4 x 32 >= 108
     constexpr int WIN = 2 * kResPS;                        // coarse planes of one (part, half) quadruple: two skip-plane windows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
     //      (buffer loads: lane offset in one VGPR, the fragment's offset as SGPR / immediate - flat addresses cost a VGPR pair per 4 KB)
     const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.wc0)) + (size_t)w * 32768, 0, 32768, 0x00020000);
     const unsigned wlane = (unsigned)lane * 16u;
-    half8 ring[kU0Ring][NPP][2];
+    half8 ring[RING][NPP][2];
     auto wload = [&](int slot, int s) {
 #pragma unroll
         for (int pt2 = NPP - 1; pt2 >= 0; --pt2)           // (the lo parts first: their product is issued first)
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
                 // (experiment switch kU0Rot: k-step order rotated by the tile's index inside its image)
         const int rot = kU0Rot ? ((t - n * tpi) & 7) : 0;
 #pragma unroll
-        for (int s = 0; s < kU0Ring; ++s) wload(s, (s + rot) & 7);                        // the first two k-steps' weights (behind the previous tile's stores in the vmcnt order)
+        for (int s = 0; s < RING; ++s) wload(s, (s + rot) & 7);                        // the first two k-steps' weights (behind the previous tile's stores in the vmcnt order)
         {
             f32x4 csa, csb, cta, ctb;
             gather8(nsc, 8 * cg, csa, csb); gather8(ntc, 8 * cg, cta, ctb);
@@ -240,19 +240,19 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[s % kU0Ring][1][cb], fx[pb][0], acc[cb][pb], 0, 0, 0);
+                    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[s % RING][1][cb], fx[pb][0], acc[cb][pb], 0, 0, 0);
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[s % kU0Ring][0][cb], fx[pb][1], acc[cb][pb], 0, 0, 0);
+                    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[s % RING][0][cb], fx[pb][1], acc[cb][pb], 0, 0, 0);
             }
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[s % kU0Ring][0][cb], fx[pb][0], acc[cb][pb], 0, 0, 0);
-            if (s + kU0Ring < 8) {                                // (fenced: the scheduler otherwise sinks the loads next to their use two k-steps
+                for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[s % RING][0][cb], fx[pb][0], acc[cb][pb], 0, 0, 0);
+            if (s + RING < 8) {                                // (fenced: the scheduler otherwise sinks the loads next to their use two k-steps
                 __builtin_amdgcn_sched_barrier(0);          //  later - a full L2 round trip per fragment in front of its MFMAs)
-                wload(s % kU0Ring, (s + kU0Ring + rot) & 7);
+                wload(s % RING, (s + RING + rot) & 7);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

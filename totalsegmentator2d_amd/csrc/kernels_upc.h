@@ -191,6 +191,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
                         rb[tap][nt][0] = *reinterpret_cast<const half8*>(wnext + tap * WT1 + nt * 512);
                         rb[tap][nt][1] = *reinterpret_cast<const half8*>(wnext + tap * WT1 + nt * 512 + 2 * BN * 16);
                     }
+                    __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the reloads next to their use four taps later: kernels_up0.h)
                 }
             }
             __builtin_amdgcn_s_setprio(0);

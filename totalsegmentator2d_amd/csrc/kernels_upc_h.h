@@ -117,6 +117,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
                         for (int nt = 0; nt < NT; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], rb[tap][nt], acc_c[mt][nt], 0, 0, 0);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) rb[tap][nt] = *reinterpret_cast<const half8*>(wnext + tap * WT1 + nt * 512);
+                    __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the reload next to its use four taps later: kernels_up0.h)
                 }
             }
             __builtin_amdgcn_s_setprio(0);
