@@ -1154,6 +1154,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 ra.oscale = wts + op.dev_ws; ra.dst = dst.data; ra.part = e->d_part;
                 ra.B = B; ra.H = Ht; ra.W = Wt; ra.tiles_x = Wt / 32; ra.tiles_y = Ht / 8; ra.n_tiles = B * ra.tiles_x * ra.tiles_y;
                 ra.slope = a.leaky_slope;
+                ra.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
                 // segment = the largest divisor of the tiles of one image that still leaves >= 2 workgroups per CU (or all tiles)
                 const int tpi_r = ra.tiles_x * ra.tiles_y, want = std::min(ra.n_tiles, 2 * e->num_cus);
                 int seg = 1;

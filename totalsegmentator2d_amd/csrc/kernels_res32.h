@@ -34,6 +34,7 @@ struct Res32Args {
     int seg;               // tiles per workgroup segment; divides tiles_x * tiles_y (a segment never leaves its image)
                            // (the statistics stay per TILE: a slice computes bit-identically alone or in a batch)
     float slope;
+    unsigned long long* prof;   // diagnostic (TS2D_DBG=256): cycles of wave 0 in [0] patch conversion, [1] barrier, [2] MFMAs, [3] epilogue, [4] barrier + tile partial
 };
 
 constexpr int kResPW = 34, kResP = 340, kResPS = 352 * 16;      // patch 10 x 34 pixels; plane stride (bytes)
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
     const f32x4 nta = *reinterpret_cast<const f32x4*>(pt), ntb = *reinterpret_cast<const f32x4*>(pt + 4);
     const f32x4 slope4 = f32x4{a.slope, a.slope, a.slope, a.slope};
 
+    TS2D_PROF_DECL(a.prof);
     for (int t = t0; t < t1; ++t) {
         // ---- patch: InstanceNorm + LeakyReLU on the fly, split into fp16 hi / lo, written k-group major
 #pragma unroll
@@ -162,7 +164,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
                     if (NPP == 2) *reinterpret_cast<uint4*>(d + 4 * kResPS) = uint4{0u, 0u, 0u, 0u};
                 }
         }
+        TS2D_STAMP_AT(a.prof, 0)
         lds_barrier();                                     // patch (and, first tile, the weights) visible to every wave
+        TS2D_STAMP_AT(a.prof, 1)
 
         // ---- next tile of the segment (one row down, or the top of the next column): prefetch its raw patch behind the MFMAs
         int ntx = txi, nty = tyi + 1;
@@ -206,6 +210,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
                 for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb][0], fx[pb][0], acc[cb][pb], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
+        TS2D_STAMP_AT(a.prof, 2)
 
         // ---- epilogue: lane = pixel j of block pb, channels 16 cb + 4 g .. + 3: one 16-byte (fp16: 8-byte) store per block
         f32x4 ov[2][4];
@@ -267,6 +272,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
                 }
             }
         }
+        TS2D_STAMP_AT(a.prof, 3)
         lds_barrier();                                     // every wave is done with the patch; the scratch is complete (stores in flight)
         if (tid < 32) {                                    // tile partial (fixed order over the 4 waves, rebased onto wave 0's pivot)
             const int co = tid, cb = co >> 4, gg = (co >> 2) & 3, i = co & 3;
@@ -287,8 +293,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) asm volatile("" :: "v"(ov[cb][pb]));      // store data registers untouched up to here
         txi = ntx; tyi = nty;
+        TS2D_STAMP_AT(a.prof, 4)
     }
-
+    TS2D_PROF_FLUSH(a.prof)
 }
 
 }  // namespace ts2d
