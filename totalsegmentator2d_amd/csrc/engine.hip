@@ -711,6 +711,7 @@ hipError_t launch_split_s2(bool f16, int bn, int maxu, const ConvArgs& a, int gr
 // per-tile partials -> scale / shift; the tile-lane count depends on the layer geometry only (never on B)
 template <typename... A>
 void launch_finalize(int B, int cout, hipStream_t st, const float* part, int ntiles, A... rest) {
+    // (8-channel blocks - four times the grid for the 32- / 64-channel levels - measured no faster: 13.2 vs 12.5 us)
     if (ntiles >= 128) hipLaunchKernelGGL(finalize_stats_t<32>, dim3(B, cout / 32), dim3(1024), 0, st, part, ntiles, rest...);
     else hipLaunchKernelGGL(finalize_stats_t<8>, dim3(B, cout / 32), dim3(256), 0, st, part, ntiles, rest...);
 }

@@ -324,18 +324,29 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
 // (a) from the conv epilogue's per-tile shifted partials (S, Q, K, n) - see "InstanceNorm partial statistics" above.  Grid (B, C/32), 32 TL threads = TL tile lanes x 32
 // channels (TL = 32 for the levels with hundreds of tiles per image: a 64-block grid is latency-bound, so each block brings 1024
 // threads; TL = 8 otherwise); fixed summation order -> bit-reproducible, and independent of the batch a slice travels in.
-template <int TL>
-__global__ __launch_bounds__(32 * TL) void finalize_stats_t(const float* __restrict__ part, int ntiles, int C, int B, int HW,
+template <int TL, int CG = 32>      // CG channels per block (8: four times the blocks for the 32- and 64-channel levels, whose grids would leave most CUs idle)
+__global__ __launch_bounds__(CG * TL) void finalize_stats_t(const float* __restrict__ part, int ntiles, int C, int B, int HW,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, float* __restrict__ scale, float* __restrict__ shift) {
-    const int n = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, tl = threadIdx.x >> 5;
-    __shared__ double rs[TL][32], rq[TL][32];
+    const int n = blockIdx.x, cl = threadIdx.x % CG, c = blockIdx.y * CG + cl, tl = threadIdx.x / CG;
+    __shared__ double rs[TL][CG], rq[TL][CG];
     const f32x4* p = reinterpret_cast<const f32x4*>(part) + (size_t)n * ntiles * C + c;
     double s = 0.0, q = 0.0;
-    for (int t = tl; t < ntiles; t += TL) {          // (S, Q, K, n) -> sum(v), sum(v^2): everything that involves the pivot, in double
-        const f32x4 v = p[(size_t)t * C];
-        const double k = (double)v[2], nn = (double)v[3];
-        s += (double)v[0] + nn * k; q += (double)v[1] + k * (2.0 * (double)v[0] + nn * k);
+    // (S, Q, K, n) -> sum(v), sum(v^2): everything that involves the pivot, in double.  Eight partials are REQUESTED before the first
+    // is added (same order of additions): the plain loop was one memory round trip per partial - 17-31 us per level-0 launch
+    for (int t0 = tl; t0 < ntiles; t0 += 8 * TL) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + j * TL;
+            v[j] = p[(size_t)(t < ntiles ? t : tl) * C];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (t0 + j * TL < ntiles) {
+                const double k = (double)v[j][2], nn = (double)v[j][3];
+                s += (double)v[j][0] + nn * k; q += (double)v[j][1] + k * (2.0 * (double)v[j][0] + nn * k);
+            }
     }
     rs[tl][cl] = s; rq[tl][cl] = q;
     __syncthreads();
@@ -392,7 +403,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restri
     for (int p = pl; p < HW; p += 8) {
         const size_t o = ((size_t)n * HW + p) * C + c;
         float v = 0.f;
-        for (int k = 0; k < S; ++k) v += partial[(size_t)k * slice_stride + o];
+        for (int k0 = 0; k0 < S; k0 += 8) {             // the partials of 8 splits requested together, added in the fixed order k = 0, 1, ...
+            float pk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = partial[(size_t)(k0 + j < S ? k0 + j : k0) * slice_stride + o];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (k0 + j < S) v += pk[j];
+        }
         v += b;
         dst[o] = (ST)v;
         v = (float)(ST)v;
