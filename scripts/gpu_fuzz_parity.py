@@ -50,7 +50,8 @@ for t in range(n):
     K = int(rng.integers(1, 27)); cin = int(rng.integers(1, 4))
     mult = 2 ** (ns - 1)
     H = mult * int(rng.integers(1, max(2, 160 // mult) + 1)); W = mult * int(rng.integers(1, max(2, 160 // mult) + 1))
-    if (H >> (ns - 1)) * (W >> (ns - 1)) < 2: W *= 2
+    while (H >> (ns - 1)) * (W >> (ns - 1)) < 4: W *= 2       # (an InstanceNorm over 2 pixels is ill-conditioned: the torch fp32 oracle itself is
+                                                              #  2.8e-4 from a float64 forward on such a case - seed 32, case 6)
     B = int(rng.integers(1, 6))
     arch = cases.unet(ns, feats, K, cin=cin, nconv=int(rng.integers(1, 3)))
     sd = weights.synthetic_state_dict(arch, 100 + t); blob = weights.pack_blob(arch, sd)
