@@ -341,6 +341,36 @@ def test_level0_composed_block_runs_the_dedicated_kernel(monkeypatch):
         assert np.abs(d16).max() <= 0.05 and np.sqrt(np.mean(d16 ** 2)) <= 5e-3, (float(np.abs(d16).max()), H, W)
 
 
+def test_f16_composed_block_on_16x32_tiles(monkeypatch):
+    """kernels_upc_h2.h: the 16-bit composed decoder entry with four M tiles per wave (16 x 32 output tiles, skip-half weights by
+    LDS-DMA).  Must be the kernel that serves the 64-column blocks on complete 16 x 32 tiles; compared with conv3x3_upc_h
+    (TS2D_UH2=0: same arithmetic, other summation order) and the oracle, transposed-conv bias x 40 (border variants), tiles on every
+    border, one and several tiles per image, KS = 2 and 4 (128 / 64 coarse channels per barrier pair)."""
+    from oracle import torch_oracle as O
+    from totalsegmentator2d_amd import weights
+    for arch, B, H, W, seed in ((cases.unet(3, (64, 64, 128), 5, cin=1), 2, 64, 64, 51),        # levels 0 and 1 compose (KS = 4, 2 x 4 and 1 x 2 tiles)
+                                (cases.unet(3, (64, 96, 160), 3, cin=2), 1, 32, 128, 52)):       # Cb = 96: KS = 2; 4 x 2 tiles, all of them border tiles
+        sd = weights.synthetic_state_dict(arch, seed)
+        for k in sd:
+            if 'transpconvs' in k and k.endswith('bias'):
+                sd[k] = (sd[k] * 40.0).astype(np.float32)
+        blob = weights.pack_blob(arch, sd)
+        x = cases.make_input(arch, B, H, W, seed)
+        ref = O.unet_forward(arch, sd, x).numpy()
+        out = {}
+        for uh2 in ('1', '0'):
+            monkeypatch.setenv('TS2D_UH2', uh2)
+            with Engine(arch, blob) as e:
+                e.set_precision('f16')
+                e.set_profiling(True)
+                lg, _ = e.forward(x, logits=True)
+                out[uh2] = (lg, e.op_kernels()['dec0.c0'])
+        assert out['1'][1] == 'conv3x3_upc_h2' and out['0'][1] == 'conv3x3_upc_h<64>'
+        d = out['1'][0] - out['0'][0]
+        assert np.abs(d).max() <= 0.05 and np.sqrt(np.mean(d ** 2)) <= 5e-3, float(np.abs(d).max())
+        assert np.abs(out['1'][0] - ref).max() <= 0.3 and np.sqrt(np.mean((out['1'][0] - ref) ** 2)) <= 0.03
+
+
 def test_randomised_shapes_against_the_torch_oracle():
     """A fixed-seed slice of scripts/gpu_fuzz_parity.py: random small architectures, channel counts, batch sizes and ragged
     extents (complete and partial pixel tiles, one- and multi-image tiles, power-of-two and other tilings), all three modes."""

@@ -18,6 +18,7 @@
 #include "kernels_up0.h"
 #include "kernels_upq.h"
 #include "kernels_upc_h.h"
+#include "kernels_upc_h2.h"
 #include "kernels_sw.h"
 #include "kernels_project.h"
 
@@ -139,6 +140,7 @@ struct ts2d_engine {
     int upq_min = 256;            // TS2D_UPQ_MIN: least coarse channel count served by conv3x3_upq
     int q16_var = 0;              // TS2D_Q16V: experiment switches of conv3x3_f16x3_qp16
     bool use_q16 = false;         // TS2D_Q16=1: ... on v_mfma_f32_16x16x32_f16 (conv3x3_f16x3_qp16: measured 1.5-10 % slower than the 32x32x16 form, opt-in)
+    bool use_uh2 = true;          // 16-bit composed block on 16 x 32 tiles (TS2D_UH2=0: conv3x3_upc_h)
     bool use_up0 = true;          // dedicated persistent kernel of the level-0 composed block (TS2D_UP0=0: conv3x3_upc<32>)
     bool use_upq = true;          // 512-thread double-buffered variant of the composed block on 16 x 32 tiles (TS2D_UPQ=0: conv3x3_upc)
     bool use_upc = true;          // decoder c0 blocks composed with their transposed conv (TS2D_UPC=0 falls back to two kernels)
@@ -1053,6 +1055,18 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_up0<float, 3>), done0));
                     hipLaunchKernelGGL((conv3x3_up0<float, 3>), dim3(u0.n_tiles / seg), dim3(kBlock), 9 * 2 * 4 * 512 + 8 * kResPS, st, u0);
                 }
+            } else if (f16 && e->use_uh2 && bn == 64 && Ht % 16 == 0 && pow2(Wt / 32) && pow2((Wt / 32) * (Ht / 16))) {
+                // 16-bit mode on 16 x 32 tiles: four M tiles per wave, skip-half weights by DMA (kernels_upc_h2.h)
+                const int ks = up.cin % 64 == 0 ? 4 : 2;
+                ua.tiles_y = Ht / 16; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y;
+                ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
+                const int grid2 = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
+                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_upc_h2");
+                static std::atomic<uint64_t> doneh4{0}, doneh2{0};
+                if (ks == 4) { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h2<4>), doneh4));
+                               hipLaunchKernelGGL(conv3x3_upc_h2<4>, dim3(grid2), dim3(kBlock), kUh2Lds, st, ua); }
+                else { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h2<2>), doneh2));
+                       hipLaunchKernelGGL(conv3x3_upc_h2<2>, dim3(grid2), dim3(kBlock), kUh2Lds, st, ua); }
             } else if (f16) {       // 16-bit mode: fp16 storage, one product (kernels_upc_h.h)
                 const int ks = up.cin % 64 == 0 ? 4 : 2;
                 const size_t smem_h = std::max((size_t)ks * 2 * kUcPlane, (size_t)4 * kUsPlane + (size_t)2 * 9 * 2 * bn * 16);
@@ -1362,6 +1376,7 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_UPQ_MIN")) e->upq_min = atoi(getenv("TS2D_UPQ_MIN"));
         if (getenv("TS2D_UPQ")) e->use_upq = getenv("TS2D_UPQ")[0] == '1';
         if (getenv("TS2D_UP0")) e->use_up0 = getenv("TS2D_UP0")[0] == '1';
+        if (getenv("TS2D_UH2")) e->use_uh2 = getenv("TS2D_UH2")[0] == '1';
         if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
     }
