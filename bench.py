@@ -526,7 +526,7 @@ def main():
                         'bound': 'mfma', 'achieved': round(htf, 2), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(htf / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': None,
                         'frac_of_measured_matrix_pipe_rate': round(htf / MEASURED_F16_PIPE_TFLOPS, 4),
-                        'kernel': f'conv3x3_h32 / conv3x3_h_qp16 / conv3x3_upc_h / conv3x3_up0 / conv3x3_res32 ({len(per)} stride-1 3x3 launches/step)',
+                        'kernel': f'conv3x3_h2 / conv3x3_h32 / conv3x3_upc_h2 / conv3x3_up0 / conv3x3_res32 ({len(per)} stride-1 3x3 launches/step)',
                         'kernel_ms_per_step': round(hms, 3), 'step_ms_profiled': round(sum(ot.values()), 3),
                         'whole_step_tflops': round(hv * work['flops'] / 1e12, 1),
                         'whole_step_hbm': {'bound': 'hbm', 'achieved': round(hv * w16['act_bytes'] / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',

@@ -360,12 +360,14 @@ def test_f16_composed_block_on_16x32_tiles(monkeypatch):
         out = {}
         for uh2 in ('1', '0'):
             monkeypatch.setenv('TS2D_UH2', uh2)
+            monkeypatch.setenv('TS2D_H2', uh2)                  # the plain C -> C blocks of the same tiling (conv3x3_h2 = the skip phase alone)
             with Engine(arch, blob) as e:
                 e.set_precision('f16')
                 e.set_profiling(True)
                 lg, _ = e.forward(x, logits=True)
-                out[uh2] = (lg, e.op_kernels()['dec0.c0'])
+                out[uh2] = (lg, e.op_kernels()['dec0.c0'], e.op_kernels()['dec0.c1'])
         assert out['1'][1] == 'conv3x3_upc_h2' and out['0'][1] == 'conv3x3_upc_h<64>'
+        assert out['1'][2] == 'conv3x3_h2' and out['0'][2] == 'conv3x3_h32<64>'
         d = out['1'][0] - out['0'][0]
         assert np.abs(d).max() <= 0.05 and np.sqrt(np.mean(d ** 2)) <= 5e-3, float(np.abs(d).max())
         assert np.abs(out['1'][0] - ref).max() <= 0.3 and np.sqrt(np.mean((out['1'][0] - ref) ** 2)) <= 0.03

@@ -10,7 +10,6 @@
 #include "kernels_f16x3_one.h"
 #include "kernels_f16x3_qp.h"
 #include "kernels_f16x3_qp16.h"
-#include "kernels_h_qp16.h"
 #include "kernels_first.h"
 #include "kernels_res32.h"
 #include "kernels_s2v2.h"
@@ -75,8 +74,6 @@ struct Op {
     size_t dev_wh = 0;            // offset (floats) of the split-fp16 weights in the arena
     size_t dev_wh32 = 0;          // offset (floats) of the fp16 weights in 32-channel chunks (precision mode f16, kernels_h32.h)
     bool h32_ok = false;
-    bool q16h_ok = false;         // 16-bit mode, persistent 16x16x32 kernel (kernels_h_qp16.h): Cin, Cin_skip % 32 == 0, Cout % 64 == 0
-    size_t dev_wq16h = 0;         // its weights [chunk32][column tile 64][tap][k-group 4][column][8 halves] (the hi parts)
     size_t dev_ws = 0;            // offset (floats) of 1 / (power-of-two pre-scale of the split weights)
     size_t dev_wp = 0;            // offset (floats) of the split-fp16 weights in plane order [chunk16][column tile][tap][hi,lo][h][column][8 halves]
                                   // (conv3x3_f16x3_qp; stride-1 split_ok convs)
@@ -140,6 +137,8 @@ struct ts2d_engine {
     int upq_min = 256;            // TS2D_UPQ_MIN: least coarse channel count served by conv3x3_upq
     int q16_var = 0;              // TS2D_Q16V: experiment switches of conv3x3_f16x3_qp16
     bool use_q16 = false;         // TS2D_Q16=1: ... on v_mfma_f32_16x16x32_f16 (conv3x3_f16x3_qp16: measured 1.5-10 % slower than the 32x32x16 form, opt-in)
+    bool use_h2 = true;           // 16-bit plain C -> C blocks on 16 x 32 tiles (TS2D_H2=0: conv3x3_h32); h2_min: least channel count
+    int h2_min = 64;
     bool use_uh2 = true;          // 16-bit composed block on 16 x 32 tiles (TS2D_UH2=0: conv3x3_upc_h)
     bool use_up0 = true;          // dedicated persistent kernel of the level-0 composed block (TS2D_UP0=0: conv3x3_upc<32>)
     bool use_upq = true;          // 512-thread double-buffered variant of the composed block on 16 x 32 tiles (TS2D_UPQ=0: conv3x3_upc)
@@ -287,7 +286,6 @@ int build_program(ts2d_engine* e) {
             if (op.stride == 1 && op.cin % 32 == 0 && op.cin_skip % 32 == 0) {      // [chunk32][column tile][tap][column][32 halves]
                 op.h32_ok = true;
                 op.dev_wh32 = wo; wo = align_up(wo + (size_t)(ct / 32) * 9 * op.cout * 16, 64);
-                if (op.cout % 64 == 0) { op.q16h_ok = true; op.dev_wq16h = wo; wo = align_up(wo + (size_t)(ct / 32) * 9 * op.cout * 16, 64); }
             }
         }
         if (op.type == OP_CONV && op.src == 0 && ct <= 4) {              // first block: PyTorch-layout fp32 copy for conv3x3_first
@@ -426,8 +424,6 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                                 rw[((((size_t)tap * 2 + 0) * 4 + ci / 8) * 32 + co) * 8 + ci % 8] = hi;
                                 rw[((((size_t)tap * 2 + 1) * 4 + ci / 8) * 32 + co) * 8 + ci % 8] = lo;
                             }
-                            if (op.q16h_ok)         // [chunk32][column tile 64][tap][k-group][column][8]: the hi parts, LDS order of conv3x3_h_qp16
-                                reinterpret_cast<uint16_t*>(out + op.dev_wq16h)[(((((size_t)(ci / 32) * (co_n / 64) + co / 64) * 9 + tap) * 4 + (ci % 32) / 8) * 64 + co % 64) * 8 + ci % 8] = hi;
                             if (op.h32_ok)          // same blocks with 32 real channels per record (the hi parts only)
                                 reinterpret_cast<uint16_t*>(out + op.dev_wh32)[((((size_t)(ci / 32) * (co_n / bn) + co / bn) * 9 + tap) * bn + co % bn) * 32 + ci % 32] = hi;
                         } else {       // K packed as 8 channels x 2 taps: k = 8 * (tap & 1) + (ci % 8) of k-step tap / 2
@@ -1239,21 +1235,24 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const bool one_s2 = split && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;
             const bool qtile = one && e->use_q && bn == 64 && ct_total(op) >= 64 && Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr &&      // (pays off from 4 chunks on: measured)
                                (op.skip < 0 || e->tensors[op.skip].scale != nullptr) && lg_exact(Wt / 32) >= 0 && lg_exact((Wt / 32) * (Ht / 16)) >= 0;
-            const bool qh = split && f16 && stride == 1 && e->use_q && op.q16h_ok && g.lgNIMG == 0 && img32 && ct_total(op) >= 256 && Ht % 16 == 0 && Wt % 32 == 0 &&      // (measured, gpurun r3: 0.29-0.32 vs 0.32-0.33 ms at 256 / 512 channels, no faster than conv3x3_h32 below)
-                            src.scale != nullptr && (op.skip < 0 || e->tensors[op.skip].scale != nullptr) && lg_exact(Wt / 32) >= 0 &&
-                            lg_exact((Wt / 32) * (Ht / 16)) >= 0 && lg_exact(op.cout / 64) >= 0;
-            if (qh) {
-                // 16-bit mode: the persistent pipeline on v_mfma_f32_16x16x32_f16, 32-channel chunks (kernels_h_qp16.h)
-                ca.wph = wts + op.dev_wq16h;
-                ca.n_ctiles = op.cout / 64; ca.lg_nct = lg_exact(ca.n_ctiles);
-                ca.tiles_x = Wt / 32; ca.tiles_y = Ht / 16; ca.n_mtiles = B * ca.tiles_x * ca.tiles_y;
-                ca.lg_tx = lg_exact(ca.tiles_x); ca.lg_tpi = lg_exact(ca.tiles_x * ca.tiles_y);
-                const int gridq = (ca.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
-                const int gridp = std::min(gridq, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));
-                static std::atomic<uint64_t> doneqh{0};
-                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_h_qp16), doneqh));
-                hipLaunchKernelGGL(conv3x3_h_qp16, dim3(gridp), dim3(kQThreads), kQ16Lds, st, ca);
-                le = hipGetLastError(); prof_kernel(e, "conv3x3_h_qp16");
+            const bool h2 = split && f16 && stride == 1 && e->use_h2 && op.cout % 64 == 0 && op.skip < 0 && ct_total(op) % 32 == 0 && g.lgNIMG == 0 && img32 &&
+                            Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr && lg_exact(Wt / 32) >= 0 && lg_exact((Wt / 32) * (Ht / 16)) >= 0 &&
+                            lg_exact(op.cout / 64) >= 0 && ct_total(op) >= e->h2_min;
+            if (h2) {
+                // 16-bit mode, plain C -> C block on 16 x 32 tiles: the skip phase of conv3x3_upc_h2 (four M tiles per wave, weights by LDS-DMA)
+                UpcArgs ua{};
+                ua.xs = src.data; ua.scs = src.scale; ua.shs = src.shift; ua.Cs = src.C;
+                ua.wk = wts + op.dev_wp; ua.bvar = wts + op.dev_b; ua.oscale = wts + op.dev_ws;
+                ua.dst = dst.data; ua.part = e->d_part;
+                ua.B = B; ua.H = Ht; ua.W = Wt; ua.Cout = op.cout;
+                ua.tiles_x = Wt / 32; ua.tiles_y = Ht / 16; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y; ua.n_ctiles = op.cout / 64;
+                ua.lg_nct = ilog2(ua.n_ctiles); ua.lg_tx = ilog2(ua.tiles_x); ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
+                ua.slope = a.leaky_slope;
+                static std::atomic<uint64_t> doneh2p{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h2<4, false>), doneh2p));
+                hipLaunchKernelGGL((conv3x3_upc_h2<4, false>), dim3((ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles), dim3(kBlock), kUh2Lds, st, ua);
+                le = hipGetLastError(); prof_kernel(e, "conv3x3_h2");
+                ca.tiles_x = ua.tiles_x; ca.tiles_y = ua.tiles_y;
             } else if (qtile) {
                 // complete 16 x 32 tiles x 64 columns, normalised sources: one 512-thread workgroup per CU, patch and weights
                 // double-buffered (weights by LDS-DMA), one barrier per chunk
@@ -1300,7 +1299,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                     else hipLaunchKernelGGL(splitk_reduce_stats<float>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, ksplit, ca.kslice_stride,
                                             wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.data, dst.scale, dst.shift);
                 } else if (fused) {
-                    launch_finalize(B, op.cout, st, e->d_part, (qtile || qh) ? ca.tiles_x * ca.tiles_y : g.tiles_x * g.tiles_y,
+                    launch_finalize(B, op.cout, st, e->d_part, (qtile || h2) ? ca.tiles_x * ca.tiles_y : g.tiles_x * g.tiles_y,
                                        op.cout, B, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
                 } else {
                     launch_stats_direct(f16, B, op.cout, HW, dst.data, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift, st);
@@ -1377,6 +1376,8 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
         if (getenv("TS2D_UPQ")) e->use_upq = getenv("TS2D_UPQ")[0] == '1';
         if (getenv("TS2D_UP0")) e->use_up0 = getenv("TS2D_UP0")[0] == '1';
         if (getenv("TS2D_UH2")) e->use_uh2 = getenv("TS2D_UH2")[0] == '1';
+        if (getenv("TS2D_H2")) e->use_h2 = getenv("TS2D_H2")[0] == '1';
+        if (getenv("TS2D_H2_MIN")) e->h2_min = atoi(getenv("TS2D_H2_MIN"));
         if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
     }

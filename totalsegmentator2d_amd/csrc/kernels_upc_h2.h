@@ -17,7 +17,9 @@ namespace ts2d {
 
 constexpr int kUh2Lds = 4 * kUq2Plane + 2 * 9 * 2 * 64 * 16;      // phase 2: planes [k-step 2][h 2] + weights [k-step][tap][h][column]
 
-template <int KS>
+// UP = false: the same kernel as a PLAIN 3x3 conv of the 16-bit mode (no coarse tensor, no phase 1): xs / scs / shs / Cs = the source,
+// wk = the layer's plane-order weight image (engine.hip: dev_wp, the same layout), bvar = its bias [Cout].
+template <int KS, bool UP = true>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3_upc_h2(const UpcArgs a) {
     constexpr int BN = 64, NT = 2, MT = 4;
     constexpr int WT1 = 4 * BN * 16;                        // bytes per tap of the weight images: [hi, lo][h][column]
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_upc_h2(const UpcArgs a) {
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
     // =================================================================================== phase 1: composed up half (coarse tensor)
-    {
+    if constexpr (UP) {
         const int Hc = a.H >> 1, Wc = a.W >> 1;
         // staging: unit it = pixel pp = 128 it + 32 w + (lane & 7) + 8 (lane >> 4) of the 10 x 18 coarse patch, octet (lane >> 3) & 1
         unsigned vo[2]; int lw[2];
@@ -230,13 +232,13 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_upc_h2(const UpcArgs a) {
     const float oscale = *a.oscale;
     const size_t img_el = (size_t)a.H * a.W * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * 2), 0x00020000);
-    const bool edge = tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1;       // wave-uniform
+    const bool edge = UP && (tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1);       // wave-uniform
     float st_s[NT], st_q[NT], st_k[NT];
     float bv0[NT], bv1[NT], bv2[NT], bv3[NT], bv4[NT], bv5[NT], bv6[NT], bv7[NT], bv8[NT];       // (nine arrays: see kernels_upc.h)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const float* pb = a.bvar + n0col + nt * 32 + r;
-        bv4[nt] = pb[4 * a.Cout];
+        bv4[nt] = UP ? pb[4 * a.Cout] : pb[0];
         bv0[nt] = bv1[nt] = bv2[nt] = bv3[nt] = bv5[nt] = bv6[nt] = bv7[nt] = bv8[nt] = 0.f;
         if (edge) {
             bv0[nt] = pb[0]; bv1[nt] = pb[a.Cout]; bv2[nt] = pb[2 * a.Cout]; bv3[nt] = pb[3 * a.Cout];
