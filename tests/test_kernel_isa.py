@@ -138,3 +138,29 @@ def test_weight_rings_keep_their_lookahead(asm):
             recent = any(x.startswith(('buffer_load', 'global_load')) and 'lds' not in x for x in body[max(0, i - 12):i])
             tight += before and after and recent
         assert tight == 0, f'{frag}: {tight} ring loads are waited for right where they are issued'
+
+
+def test_wide_store_data_is_not_overwritten_right_behind_the_store(asm):
+    """gfx950 wide-store hazard (kernels_res32.h): a VALU write to the data registers of a 128-bit buffer store two instructions
+    behind it reached the stored data.  conv3x3_res32 keeps the stored vectors alive to the end of the tile; conv3x3_up0 has no registers
+    for that and pins them with wait states (`s_nop 3` that takes the vector as an operand - a bare `s_nop` was scheduled away from
+    the store and the registers were reused three instructions behind it).  Assert >= 5 instruction / wait states between a 128-bit
+    store and the first VALU write into its data registers in both fp32 kernels."""
+    for frag in ('conv3x3_up0IfLi3E', 'conv3x3_res32IfLi3E'):
+        body = _body(asm, frag)
+        for i, ln in enumerate(body):
+            if not ln.startswith('buffer_store_dwordx4'):
+                continue
+            lo, hi = map(int, re.search(r'v\[(\d+):(\d+)\]', ln).groups())
+            n = 0
+            for x in body[i + 1:i + 8]:
+                if x.endswith(':') or x.startswith(('s_cbranch', 's_branch', 's_endpgm')):
+                    break
+                if x.startswith('s_nop'):
+                    n += int(x.split()[1]) + 1
+                    continue
+                n += 1
+                m = re.match(r'v_\w+\s+v(\[(\d+):(\d+)\]|(\d+))', x)
+                if m:
+                    d0, d1 = (int(m.group(2)), int(m.group(3))) if m.group(2) else (int(m.group(4)), int(m.group(4)))
+                    assert not (d0 <= hi and d1 >= lo) or n >= 5, f'{frag}: {x} overwrites the data of `{ln}` {n} states behind it'

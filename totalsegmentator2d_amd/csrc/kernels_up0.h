@@ -378,7 +378,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
                         for (int i = 0; i < 4; ++i) { hv[i] = (_Float16)v[i]; v[i] = (float)hv[i]; }
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rsd, vst + soff, 0, kU0NT);
                     }
-                    asm volatile("s_nop 3" ::: "memory");
+                    asm volatile("s_nop 3" :: "v"(v) : "memory");      // (v as an operand: its registers stay allocated up to the wait states -
+                                                                       //  without it the scheduler moved VALU work in between and reused them 3 instructions behind the store)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { const float d = v[i] - kv[cb][i]; ss[cb][i] += d; qq[cb][i] = __builtin_fmaf(d, d, qq[cb][i]); }
                 }
