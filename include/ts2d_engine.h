@@ -80,6 +80,18 @@ int ts2d_engine_load_weights(ts2d_engine* e, const float* weights, size_t n_floa
 /* Select the arithmetic mode (see TS2D_PRECISION_*); takes effect at the next forward. */
 int ts2d_engine_set_precision(ts2d_engine* e, int mode);
 
+/* Kernel-dispatch options (ABI 6; replaces the TS2D_* environment switches of ABI <= 5 - a product library must not change kernels
+ * because of its caller's environment).  Several ops have two complete, parity-tested kernels (e.g. the decoder entry composed
+ * with its ConvTranspose2d, or as two kernels); an option picks one for THIS handle, takes effect at the next reserve / forward and
+ * never changes results beyond fp32 summation order (the parity tests run both sides of every switch).  Names (value 0 / 1 unless noted):
+ *   "upc" composed decoder entry | "upq" its 512-thread variant | "upq_min" (int) least coarse channels for it | "up0" dedicated
+ *   level-0 composed kernel | "u0seg" (int) its tiles per workgroup segment, 0 = automatic | "q" persistent 16x32-tile stride-1 kernel |
+ *   "one" one-image-tile kernels | "res" resident-weight 32 -> 32 kernel | "fuse0" first block recomputed inside the second |
+ *   "s2v2" 512-thread stride-2 kernel | "h32", "h2", "h2_min" (int), "uh2": the 16-bit mode's variants.
+ * Unknown names and out-of-range values return TS2D_ERR_INVALID.  The reference has no counterpart (one code path through torch:
+ * ts2d/core/inference/prediction_worker.py:209); the callers are this repo's tests and A/B scripts. */
+int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value);
+
 /* Weight-broadcast hook: device pointer + byte size of the packed weight arena.  Rank 0 creates with
  * weights, the other ranks with NULL; all ranks broadcast this buffer (RCCL, root 0), then call
  * ts2d_engine_weights_ready(). */
@@ -181,6 +193,16 @@ int ts2d_synth_slices(int device, unsigned long long key, unsigned long long fir
 /* Pre-allocate the activation workspace for (B, H, W) (reference warm-up contract: a zero patch is pushed through
  * the predictor once at start-up, prediction_worker.py:74-96,136-138). */
 int ts2d_engine_reserve(ts2d_engine* e, int B, int H, int W);
+
+/* Caller-provided activation workspace (ABI 6).  ts2d_engine_workspace_bytes: the bytes ts2d_engine_reserve(B, H, W) would
+ * allocate under the engine's current precision mode / options.  ts2d_engine_set_workspace: use [dev_ptr, dev_ptr + n_bytes) (256-byte
+ * aligned device memory owned by the caller, alive until it is replaced or the engine destroyed) instead of an allocation of the
+ * engine's own; dev_ptr = NULL returns to that.  A forward that needs more than n_bytes fails with TS2D_ERR_NOMEM.  Purpose: the five
+ * sub-models of ts2d-v2 run one after the other on one stream (the reference drives them sequentially, ts2d/tool.py:110-112), so ONE
+ * workspace of the largest size serves all five engines.  Engines that share a workspace must be driven on the same stream (or be
+ * ordered by the caller): the engine's own cross-stream ordering covers the runs of ONE handle only. */
+int ts2d_engine_workspace_bytes(ts2d_engine* e, int B, int H, int W, size_t* n_bytes);
+int ts2d_engine_set_workspace(ts2d_engine* e, void* dev_ptr, size_t n_bytes);
 
 /* Per-op device timing (HIP events on the launch stream).  enable != 0 brackets every kernel of subsequent forwards
  * with events; ts2d_engine_op_times returns for the LAST forward the elapsed ms per op (n_ops entries, program

@@ -17,6 +17,7 @@ Rows restated:
   A3        ``compute_steps_for_sliding_window`` / slicers                -> :func:`sliding_window_steps`
   A4        ``compute_gaussian`` + fp16 accumulation                      -> :func:`compute_gaussian`, :func:`predict_sliding_window`
   A2        fold ensembling                                               -> :func:`predict_logits`
+  (tests)   one block from given inputs                                   -> :func:`layer_forward`
   A7        multilabel export ``sigmoid(logits.float()) > 0.5``           -> :func:`logits_to_mask`
   A1        ZScoreNormalization                                           -> :func:`zscore`
 """
@@ -35,18 +36,45 @@ def _t(x):
 
 
 # ----------------------------------------------------------------------------- K1-K7 / A6
-def conv_block(x, w, b, g, be, stride, eps=1e-5, slope=0.01):
-    """``ConvDropoutNormReLU``: Conv2d(3x3, pad 1, stride) -> InstanceNorm2d(affine, eps, biased var) -> LeakyReLU."""
-    y = F.conv2d(x, w, b, stride=stride, padding=1)
+def _h(t):
+    """Round to IEEE half and back: what a value becomes when the 16-bit mode stores it (or feeds it to an fp16 MFMA operand)."""
+    return t.to(torch.float16).to(torch.float32)
+
+
+def conv_block(x, w, b, g, be, stride, eps=1e-5, slope=0.01, emulate=None, round_w=True, storage_view=False):
+    """``ConvDropoutNormReLU``: Conv2d(3x3, pad 1, stride) -> InstanceNorm2d(affine, eps, biased var) -> LeakyReLU.
+
+    ``emulate='f16'`` restates the arithmetic CONTRACT of the engine's 16-bit mode (include/ts2d_engine.h, TS2D_PRECISION_F16; to first
+    order also the reference's CUDA path, which runs the network under fp16 autocast: ``ts2d/core/inference/nnu.py:159-163``):
+    weights rounded to fp16 once, products accumulated in fp32 (F.conv2d on fp16-representable fp32 tensors), bias added in fp32, the
+    conv output STORED as fp16, InstanceNorm statistics in fp32 over the stored values, the normalised value rounded to fp16 and the
+    LeakyReLU done in fp16 (``max(y, fp16(y * fp16(slope)))``) - the operand the next conv multiplies.  ``round_w=False``: the first
+    block, which the engine computes from the fp32 network input with fp32 weights (exact fp32 MFMA) and only stores as fp16.
+    ``storage_view=True``: the block's output as the engine's debug accessor shows it - the STORED fp16 conv output normalised and
+    activated in fp32, without the operand rounding of the consumer - so that a per-layer comparison is not blurred by half an fp16
+    ulp on every element."""
+    if emulate is None:
+        y = F.conv2d(x, w, b, stride=stride, padding=1)
+        y = F.instance_norm(y, None, None, g, be, use_input_stats=True, momentum=0.1, eps=eps)
+        return F.leaky_relu(y, slope)
+    assert emulate == 'f16'
+    y = _h(F.conv2d(x, _h(w) if round_w else w, b, stride=stride, padding=1))
     y = F.instance_norm(y, None, None, g, be, use_input_stats=True, momentum=0.1, eps=eps)
-    return F.leaky_relu(y, slope)
+    if storage_view:
+        return F.leaky_relu(y, slope)
+    y = _h(y)
+    s16 = float(torch.tensor(slope, dtype=torch.float16))
+    return torch.maximum(y, _h(y * s16))
 
 
-def unet_forward(arch, sd: Dict[str, np.ndarray], x, return_intermediates: bool = False):
+def unet_forward(arch, sd: Dict[str, np.ndarray], x, return_intermediates: bool = False, emulate=None):
     """``PlainConvUNet.forward`` (deep supervision off): encoder stages (strided first conv), then per decoder
-    stage ``transpconv -> cat((up, skip), 1) -> conv blocks``, finally ``seg_layers[-1]``.  x: [B,C,H,W] fp32."""
+    stage ``transpconv -> cat((up, skip), 1) -> conv blocks``, finally ``seg_layers[-1]``.  x: [B,C,H,W] fp32.
+    ``emulate='f16'``: the 16-bit mode's contract (see :func:`conv_block`); the transposed conv's output is stored as fp16 without
+    normalisation, the head multiplies fp16 weights with the fp16 activations and returns fp32 logits."""
     sd = {k: _t(v) for k, v in sd.items()}
     x = _t(x).to(torch.float32)
+    f16 = emulate == 'f16'
     inter = {}
     skips = []
     with torch.no_grad():
@@ -54,23 +82,65 @@ def unet_forward(arch, sd: Dict[str, np.ndarray], x, return_intermediates: bool 
             for i in range(arch.n_conv_per_stage[s]):
                 k = f'encoder.stages.{s}.0.convs.{i}'
                 x = conv_block(x, sd[f'{k}.conv.weight'], sd[f'{k}.conv.bias'], sd[f'{k}.norm.weight'],
-                               sd[f'{k}.norm.bias'], 2 if (i == 0 and s > 0) else 1, arch.norm_eps, arch.leaky_slope)
+                               sd[f'{k}.norm.bias'], 2 if (i == 0 and s > 0) else 1, arch.norm_eps, arch.leaky_slope,
+                               emulate=emulate, round_w=not (s == 0 and i == 0))
                 inter[f'enc{s}.c{i}'] = x
             skips.append(x)
         for j in range(arch.n_stages - 1):
             lvl = arch.n_stages - 2 - j
             k = f'decoder.transpconvs.{j}'
-            x = F.conv_transpose2d(x, sd[f'{k}.weight'], sd[f'{k}.bias'], stride=2)
+            if f16:
+                x = _h(F.conv_transpose2d(x, _h(sd[f'{k}.weight']), sd[f'{k}.bias'], stride=2))
+            else:
+                x = F.conv_transpose2d(x, sd[f'{k}.weight'], sd[f'{k}.bias'], stride=2)
             inter[f'dec{lvl}.up'] = x
             x = torch.cat((x, skips[lvl]), 1)
             for i in range(arch.n_conv_per_stage_decoder[j]):
                 k = f'decoder.stages.{j}.convs.{i}'
                 x = conv_block(x, sd[f'{k}.conv.weight'], sd[f'{k}.conv.bias'], sd[f'{k}.norm.weight'],
-                               sd[f'{k}.norm.bias'], 1, arch.norm_eps, arch.leaky_slope)
+                               sd[f'{k}.norm.bias'], 1, arch.norm_eps, arch.leaky_slope, emulate=emulate)
                 inter[f'dec{lvl}.c{i}'] = x
         k = f'decoder.seg_layers.{arch.n_stages - 2}'
-        x = F.conv2d(x, sd[f'{k}.weight'], sd[f'{k}.bias'])
+        x = F.conv2d(x, _h(sd[f'{k}.weight']) if f16 else sd[f'{k}.weight'], sd[f'{k}.bias'])
     return (x, inter) if return_intermediates else x
+
+
+def layer_forward(arch, sd: Dict[str, np.ndarray], name: str, src, skip=None, emulate=None, storage_view=False):
+    """ONE block of :func:`unet_forward` in isolation, from the activated tensors it reads (as torch holds them after the previous
+    block): ``encS.cI`` / ``decL.cI`` (I > 0) from ``src``; ``decL.c0`` from ``src`` = the COARSE tensor the transposed conv reads and
+    ``skip`` (transpconv -> cat((up, skip), 1) -> conv block); ``head`` from ``src``.  Per-layer parity tests feed it the engine's own
+    inputs of that layer, so that an error cannot hide behind the accumulated difference of the layers in front of it.
+    With ``emulate='f16'`` the given inputs are rounded to fp16 first (the operand rounding of the consumer);
+    ``storage_view``: see :func:`conv_block`."""
+    sd = {k: _t(v) for k, v in sd.items()}
+    x = _t(src).to(torch.float32)
+    f16 = emulate == 'f16'
+    if f16 and name != 'enc0.c0':
+        # the engine's debug accessor returns activations BEFORE the consumer's operand rounding: round them here (a no-op for
+        # inputs taken from unet_forward(emulate='f16'); on the negative LeakyReLU branch fp16(y * 0.01f) stands in for the
+        # engine's fp16(fp16(y) * fp16(0.01)): values 100x smaller than the rest, relative difference 7e-4)
+        x = _h(x)
+        if skip is not None:
+            skip = _h(_t(skip).to(torch.float32))
+    with torch.no_grad():
+        if name == 'head':
+            k = f'decoder.seg_layers.{arch.n_stages - 2}'
+            return F.conv2d(x, _h(sd[f'{k}.weight']) if f16 else sd[f'{k}.weight'], sd[f'{k}.bias'])
+        kind, lvl, i = name[:3], int(name[3:name.index('.')]), int(name[name.index('.c') + 2:])
+        if kind == 'enc':
+            k = f'encoder.stages.{lvl}.0.convs.{i}'
+            stride = 2 if (i == 0 and lvl > 0) else 1
+            rw = not (lvl == 0 and i == 0)
+        else:
+            j = arch.n_stages - 2 - lvl
+            k = f'decoder.stages.{j}.convs.{i}'
+            stride, rw = 1, True
+            if i == 0:
+                kt = f'decoder.transpconvs.{j}'
+                up = F.conv_transpose2d(x, _h(sd[f'{kt}.weight']) if f16 else sd[f'{kt}.weight'], sd[f'{kt}.bias'], stride=2)
+                x = torch.cat((_h(up) if f16 else up, _t(skip).to(torch.float32)), 1)
+        return conv_block(x, sd[f'{k}.conv.weight'], sd[f'{k}.conv.bias'], sd[f'{k}.norm.weight'], sd[f'{k}.norm.bias'],
+                          stride, arch.norm_eps, arch.leaky_slope, emulate=emulate, round_w=rw, storage_view=storage_view)
 
 
 # ----------------------------------------------------------------------------- A7

@@ -1,8 +1,8 @@
-"""Interleaved A/B of kernel variants in ONE process on ONE device (guide rule 24): engines created under different TS2D_*
-environment switches (read at engine creation), B=64 canonical forwards alternated for several rounds, per-op HIP-event times.
+"""Interleaved A/B of kernel variants in ONE process on ONE device (guide rule 24): engines created with different dispatch options
+(ts2d_engine_set_option), B=64 canonical forwards alternated for several rounds, per-op HIP-event times.
 
-    python scripts/gpu_ab.py TS2D_Q16=0 TS2D_Q16=1 [--ops enc2.c1,dec3.c1] [--rounds 5] [--mode split]
-Each positional argument is one variant: comma-separated NAME=VALUE pairs ('-' = defaults).  Prints per variant the whole-forward
+    python scripts/gpu_ab.py - fuse0=0 [--ops enc0.c0,enc0.c1] [--rounds 5] [--mode split]
+Each positional argument is one variant: comma-separated option=value pairs ('-' = defaults).  Prints per variant the whole-forward
 time (median / min over rounds, un-profiled) and the per-op medians of the selected ops, plus max|logits A - logits B| vs variant 0."""
 import argparse, os, sys
 import numpy as np
@@ -23,15 +23,10 @@ a = UNetArch.canonical()
 blob = weights.pack_blob(a, weights.synthetic_state_dict(a, 1))
 engines = []
 for v in args.variants:
-    saved = dict(os.environ)
-    if v != '-':
-        for kv in v.split(','):
-            k, val = kv.split('=')
-            os.environ[k] = val
-    e = Engine(a, blob)
+    opts = {} if v == '-' else {kv.split('=')[0]: int(kv.split('=')[1]) for kv in v.split(',')}
+    e = Engine(a, blob, options=opts)
     e.set_precision(args.mode)
     engines.append(e)
-    os.environ.clear(); os.environ.update(saved)
 xd = torch.randn(args.batch, 2, 512, 512, device='cuda')
 lg = torch.empty(args.batch, 18, 512, 512, device='cuda')
 outs = []

@@ -93,7 +93,7 @@ def test_input_offset_puts_the_mean_far_above_sigma_at_the_first_layer():
             assert np.isfinite(lg).all() and _rel_err(lg, ref.numpy()) <= 1e-4, (mode, _rel_err(lg, ref.numpy()))
 
 
-def test_overflowing_transposed_conv_output_is_an_error_naming_the_layer(monkeypatch):
+def test_overflowing_transposed_conv_output_is_an_error_naming_the_layer():
     arch, sd, x = _case()
     blob_ok = weights.pack_blob(arch, sd)
     sd = dict(sd)
@@ -107,8 +107,7 @@ def test_overflowing_transposed_conv_output_is_an_error_naming_the_layer(monkeyp
         lg, _ = e.forward(x)                               # (level 1 of this case is 32 x 32: complete tiles, composed)
         assert not e.materialised('dec1.up')
         assert np.isfinite(lg).all() and _rel_err(lg, ref) <= 1e-4
-    monkeypatch.setenv('TS2D_UPC', '0')                    # two-kernel path: the overflow is detected and named
-    with Engine(arch, blob) as e:
+    with Engine(arch, blob, options={'upc': 0}) as e:      # two-kernel path: the overflow is detected and named
         with pytest.raises(RuntimeError, match=r'non-finite logits: inf / NaN first appears in layer dec1\.c0'):
             e.forward(x)                                   # host-buffer forward runs ts2d_engine_check itself
         import torch

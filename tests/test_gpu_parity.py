@@ -14,13 +14,32 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+THR = 1.5 * 2.0 ** -24          # sigmoid(float(x)) > 0.5  <=>  x > 1.5 * 2^-24 (tests/test_oracle.py pins the predicate)
+
+
 def _oracle_mask(logits):
     from oracle import c_oracle as C
     return C.logits_to_mask(logits)
 
 
+def assert_flips_are_tolerance_flips(lg, ref, mask_u8, ref_mask_u8):
+    """Mask bits may differ from the oracle's end to end ONLY where the oracle's logit lies within the slice's logit error of the
+    threshold: a flipped bit at |oracle logit| = 0.3 is a bug, not a tolerance flip.  Returns (#flips, the
+    largest |oracle logit - threshold| among them)."""
+    lg, ref = np.asarray(lg), np.asarray(ref)
+    diff = np.asarray(mask_u8) != np.asarray(ref_mask_u8)
+    worst = 0.0
+    for b in range(lg.shape[0]):
+        if diff[b].any():
+            err = float(np.abs(lg[b] - ref[b]).max())
+            dist = float(np.abs(ref[b][diff[b]].astype(np.float64) - THR).max())
+            assert dist <= err, f'slice {b}: a mask bit differs from the oracle at |oracle logit - thr| = {dist:.3e} > logit error {err:.3e}'
+            worst = max(worst, dist)
+    return int(diff.sum()), worst
+
+
 @pytest.mark.parametrize('name', list(cases.SMALL_CASES))
-def test_logits_and_masks_match_goldens(name, monkeypatch):
+def test_logits_and_masks_match_goldens(name):
     arch, B, H, W, seed = cases.SMALL_CASES[name]
     _, blob = blob_for(arch, seed)
     x = cases.make_input(arch, B, H, W, seed)
@@ -39,6 +58,8 @@ def test_logits_and_masks_match_goldens(name, monkeypatch):
             assert np.array_equal(unpack_mask(mk, W), _oracle_mask(lg))            # bit-exact on the same logits
             disagree = int((mk.view(np.uint32) != g['mask_packed']).sum())
             assert disagree <= max(2, lg.size // 20000)                              # vs oracle end-to-end: only |logit| ~ 1e-5 flips
+            if name != 'tiny_b37':                                                   # ... and every one of them within the logit error of the threshold
+                assert_flips_are_tolerance_flips(lg, g['logits'], unpack_mask(mk, W), unpack_mask(g['mask_packed'], W))
         inter = [k for k in g.files if k.startswith('inter/')]
         composed = [k for k in inter if k.endswith('.up') and not e.materialised(k[6:])]   # K5 composed into K6 (kernels_upc.h)
         for k in inter:                                                               # per-kernel parity K1..K7
@@ -46,8 +67,7 @@ def test_logits_and_masks_match_goldens(name, monkeypatch):
                 t = e.debug_tensor(k[6:])
                 assert t.shape == g[k].shape and np.abs(t - g[k]).max() <= TOL, k
     if composed:                                                                      # K5 on its own kernel: two-kernel path
-        monkeypatch.setenv('TS2D_UPC', '0')
-        with Engine(arch, blob) as e:
+        with Engine(arch, blob, options={'upc': 0}) as e:
             lg0, _ = e.forward(x, logits=True)
             for k in inter:
                 t = e.debug_tensor(k[6:])
@@ -99,7 +119,8 @@ def test_full_batch_properties_config2():
         assert torch.equal(packed, mk.to(torch.int64) & 0xFFFFFFFF)
         # InstanceNorm property on an intermediate: mean 0 / var 1 before the affine is hard to read after LeakyReLU,
         # so check the statistics kernel instead: enc0.c1 activations must be finite and O(1)
-        li, _ = e.forward(x[:2].contiguous(), logits=True)
+        x2 = x[:2].contiguous()                               # (the engine holds its last input weakly: keep it alive for debug_tensor)
+        li, _ = e.forward(x2, logits=True)
         t = e.debug_tensor('enc0.c1')
         assert np.isfinite(t).all() and 0.2 < float(np.abs(t).mean()) < 2.0
     # spot parity of one slice of the big batch against the torch oracle
@@ -107,6 +128,8 @@ def test_full_batch_properties_config2():
     sd, _ = blob_for(arch, 1)
     ref = O.unet_forward(arch, sd, x[37:38].cpu().numpy()).numpy()
     assert np.abs(lg[37:38].cpu().numpy() - ref).max() <= TOL
+    nflip, _ = assert_flips_are_tolerance_flips(lg[37:38].cpu().numpy(), ref, unpack_mask(mk[37:38].cpu().numpy(), 512), O.logits_to_mask(ref).numpy())
+    assert nflip <= 64
 
 
 def test_error_paths_raise_runtime_error():
@@ -184,47 +207,83 @@ def test_config5_tsxr_geometry_9_stages_1024():
 
 # ----------------------------------------------------------------------------------------------------------------------
 # "mixed fp16" mode (BASELINE configs 3 and 5: 16-bit activations/weights, fp32 accumulate, fp32 InstanceNorm statistics).
-# Relaxed tolerance, stated: logits max-abs <= 0.15 and rms <= 0.02 vs the fp32 oracle (measured on the canonical net:
-# 7.4e-2 / 7.5e-3), thresholded masks disagree on <= 1 % of the bits (measured 0.25 %).
-F16_MAX, F16_RMS, F16_MASK = 0.15, 0.02, 0.01
+# Two references, two bounds, both stated:
+#  (a) the 16-BIT oracle (oracle/torch_oracle.py: unet_forward(emulate='f16') - the mode's own arithmetic contract: fp16 weights, fp16
+#      stored activations, fp32 accumulation / statistics).  What is left between it and the engine is fp32 summation order, which can
+#      flip the fp16 rounding of single stored values, and the composed decoder entries (fp64-composed weights rounded ONCE to fp16
+#      where the oracle rounds the transposed conv's weights, its output and the 3x3 weights separately).  Measured on the MI355X
+#      (scripts/gpu_f16_oracle_err.py, numbers in DESIGN.md section 4): the bounds below are ~2x the worst case seen.
+#  (b) the fp32 oracle: how far the MODE is from fp32 (canonical net 7e-2 max / 8e-3 rms, 0.25 % of the mask bits) - a property of
+#      16-bit arithmetic, kept as a loose sanity bound only.
+F16E_MAX, F16E_RMS = 0.1, 0.012                # (a) end to end, logits
+F16_LAYER_MAX, F16_LAYER_RMS = 1.5e-2, 4e-4    # (a) ONE block, fed with the engine's own inputs of that block
+F16_MAX, F16_RMS, F16_MASK = 0.15, 0.02, 0.01  # (b)
 
 
 @pytest.mark.parametrize('name', ['k_two3', 'net5_128', 'wide64', 'xr_1ch', 'tiny_b37'])
 def test_f16_mode_small_cases(name):
+    from oracle import torch_oracle as O
     arch, B, H, W, seed = cases.SMALL_CASES[name]
-    _, blob = blob_for(arch, seed)
+    sd, blob = blob_for(arch, seed)
     x = cases.make_input(arch, B, H, W, seed)
     g = golden(name)['logits']
+    ref16, inter16 = O.unet_forward(arch, sd, x, return_intermediates=True, emulate='f16')
     with Engine(arch, blob) as e:
         e.set_precision('f16')
         lg, mk = e.forward(x, logits=True, mask=(W % 32 == 0))
+        if name != 'tiny_b37':                              # (2x2-pixel bottleneck: InstanceNorm over 4 values amplifies any rounding)
+            d = lg - ref16.numpy()
+            assert np.abs(d).max() <= F16E_MAX and np.sqrt((d ** 2).mean()) <= F16E_RMS, (float(np.abs(d).max()), float(np.sqrt((d ** 2).mean())))
         assert np.abs(lg - g).max() <= F16_MAX and np.sqrt(((lg - g) ** 2).mean()) <= F16_RMS
         if mk is not None:
             assert np.array_equal(unpack_mask(mk, W), _oracle_mask(lg))            # still bit-exact on its own logits
+        if name == 'net5_128':                              # every block of the net, from the engine's own inputs of that block
+            prog = {o['name']: o for o in arch.program()}
+            for n, o in prog.items():
+                if n.endswith('.up') or n == 'head':
+                    continue
+                if n.endswith('.c0') and n.startswith('dec'):
+                    ins = (prog[n.replace('.c0', '.up')]['src'], o['skip'])
+                else:
+                    ins = (o['src'],)
+                srcs = [x if i == 'input' else e.debug_tensor(i) for i in ins]
+                got = e.debug_tensor(n)
+                want = O.layer_forward(arch, sd, n, *srcs, emulate='f16', storage_view=True).numpy()
+                lvl_px = got.shape[2] * got.shape[3]
+                if lvl_px >= 64:                            # (below: statistics over a handful of pixels)
+                    assert np.abs(got - want).max() <= F16_LAYER_MAX and np.sqrt(np.mean((got - want) ** 2)) <= F16_LAYER_RMS, \
+                        (n, float(np.abs(got - want).max()))
+            want = O.layer_forward(arch, sd, 'head', e.debug_tensor(prog['head']['src']), emulate='f16').numpy()
+            assert np.abs(lg - want).max() <= F16_LAYER_MAX
         e.set_precision('split')                                                    # modes can be switched on a live engine
         lg2, _ = e.forward(x)
         assert np.abs(lg2 - g).max() <= (2e-3 if name == 'tiny_b37' else TOL)
 
 
 def test_config3_config5_in_f16():
-    """Config 3 (a 26-head sub-model, 512x512) and config 5 (tsxr: 1-channel 1024x1024, 9 stages) in the 16-bit mode."""
+    """Config 3 (a 26-head sub-model, 512x512) and config 5 (tsxr: 1-channel 1024x1024, 9 stages) in the 16-bit mode, against the
+    16-bit oracle (tight) and the fp32 oracle (what the mode costs)."""
     from oracle import torch_oracle as O
     for arch, hw, seed in ((UNetArch.canonical(num_classes=26), 512, 4),
                            (UNetArch.canonical(input_channels=1, num_classes=26, n_stages=9), 1024, 7)):
         sd, blob = blob_for(arch, seed)
         x = cases.make_input(arch, 1, hw, hw, seed)
         ref = O.unet_forward(arch, sd, x).numpy()
+        ref16 = O.unet_forward(arch, sd, x, emulate='f16').numpy()
         with Engine(arch, blob) as e:
             e.set_precision('f16')
             lg, mk = e.forward(x, logits=True, mask=True)
+        d = lg - ref16
+        assert np.abs(d).max() <= F16E_MAX and np.sqrt((d ** 2).mean()) <= F16E_RMS, (hw, float(np.abs(d).max()), float(np.sqrt((d ** 2).mean())))
+        assert_flips_are_tolerance_flips(lg, ref16, unpack_mask(mk, hw), O.logits_to_mask(ref16).numpy())
         assert np.abs(lg - ref).max() <= F16_MAX and np.sqrt(((lg - ref) ** 2).mean()) <= F16_RMS
         assert (unpack_mask(mk, hw) != O.logits_to_mask(ref).numpy()).mean() <= F16_MASK
 
 
-def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch):
+def test_one_image_kernels_are_bit_identical_to_the_generic_kernels():
     """The one-image-tile kernels (conv3x3_f16x3_one, conv3x3s2_f16x3_one, convT2x2_f16x3_one, first-layer fast epilogue) claim
     the arithmetic and summation order of the generic kernels: every convolution output must be bit-identical with them switched
-    off (TS2D_ONE=0, read when the engine is created).  The head differs by design (matrix-core head vs plain FMA chain)."""
+    off (option "one" = 0).  The head differs by design (matrix-core head vs plain FMA chain)."""
     arch, B, H, W, seed = cases.SMALL_CASES['net5_128']
     _, blob = blob_for(arch, seed)
     x = cases.make_input(arch, B, H, W, seed)
@@ -232,15 +291,13 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
     with Engine(arch, blob) as e:                          # default path: includes the resident-weight 32 -> 32 kernel
         lgr, _ = e.forward(x, logits=True)
         tr = {n: e.debug_tensor(n) for n in names}
-    monkeypatch.setenv('TS2D_RES', '0')                    # (conv3x3_res32, conv3x3s2_v2 and conv3x3_upc sum in another order: compared by value below)
-    monkeypatch.setenv('TS2D_S2V2', '0')
-    monkeypatch.setenv('TS2D_UPC', '0')
-    monkeypatch.setenv('TS2D_Q', '0')                      # (conv3x3_f16x3_q: same conv outputs, statistics summed over other tiles)
-    with Engine(arch, blob) as e:
+    # (conv3x3_res32, conv3x3s2_v2 and conv3x3_upc sum in another order: compared by value below;
+    #  conv3x3_f16x3_qp: same conv outputs, statistics summed over other tiles)
+    off = {'res': 0, 's2v2': 0, 'upc': 0, 'q': 0, 'fuse0': 0}
+    with Engine(arch, blob, options=off) as e:
         lg1, _ = e.forward(x, logits=True)
         t1 = {n: e.debug_tensor(n) for n in names}
-    monkeypatch.setenv('TS2D_ONE', '0')
-    with Engine(arch, blob) as e:
+    with Engine(arch, blob, options=dict(off, one=0)) as e:
         lg0, _ = e.forward(x, logits=True)
         t0 = {n: e.debug_tensor(n) for n in names}
     for n in names:
@@ -253,9 +310,9 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels(monkeypatch)
     assert np.abs(lgr - lg1).max() <= 2e-5
 
 
-def test_composed_upsampling_block_matches_the_two_kernel_path_and_the_oracle(monkeypatch):
+def test_composed_upsampling_block_matches_the_two_kernel_path_and_the_oracle():
     """kernels_upc.h / kernels_upq.h: ConvTranspose2d composed into the "up" half of the next 3x3 conv (parity-specific 2x2 weights over the
-    coarse tensor, nine bias variants for the image border).  Checked against the two-kernel path (TS2D_UPC=0) layer by layer and
+    coarse tensor, nine bias variants for the image border).  Checked against the two-kernel path (option "upc" = 0) layer by layer and
     against the torch oracle, with the transposed conv's BIAS blown up so that a wrong border variant cannot hide, on extents
     where some levels compose (complete 8 x 32 tiles) and others do not, one and several tiles per image, BN = 32 and 64."""
     from oracle import torch_oracle as O
@@ -273,15 +330,13 @@ def test_composed_upsampling_block_matches_the_two_kernel_path_and_the_oracle(mo
         x = cases.make_input(arch, B, H, W, seed)
         ref = O.unet_forward(arch, sd, x).numpy()
         names = [f'dec{l}.c0' for l in range(arch.n_stages - 1)]
-        monkeypatch.delenv('TS2D_UPC', raising=False)
         with Engine(arch, blob) as e:
             lg1, _ = e.forward(x, logits=True)
             t1 = {n: e.debug_tensor(n) for n in names}
             with pytest.raises(Exception, match='not materialised'):
                 e.debug_tensor('dec0.up')
             e.check()
-        monkeypatch.setenv('TS2D_UPC', '0')
-        with Engine(arch, blob) as e:
+        with Engine(arch, blob, options={'upc': 0}) as e:
             lg0, _ = e.forward(x, logits=True)
             t0 = {n: e.debug_tensor(n) for n in names}
             e.debug_tensor('dec0.up')
@@ -290,10 +345,10 @@ def test_composed_upsampling_block_matches_the_two_kernel_path_and_the_oracle(mo
         assert np.abs(lg1 - ref).max() <= TOL and np.abs(lg0 - ref).max() <= TOL
 
 
-def test_level0_composed_block_runs_the_dedicated_kernel(monkeypatch):
+def test_level0_composed_block_runs_the_dedicated_kernel():
     """kernels_up0.h: the 64 -> (32 | 32) -> 32 decoder entry of the canonical level 0 as a persistent kernel (resident skip weights,
     composed weights streamed in fragment order, 16x16x32 transposed product).  The kernel must be the one that serves dec0.c0 in
-    the split and the 16-bit mode; its output is checked against conv3x3_upc (TS2D_UP0=0), the two-kernel path (TS2D_UPC=0) and the
+    the split and the 16-bit mode; its output is checked against conv3x3_upc (option "up0" = 0), the two-kernel path ("upc" = 0) and the
     oracle on an extent with border tiles on all four sides, one tile per image column, and a segment that ends inside an image."""
     from oracle import torch_oracle as O
     from totalsegmentator2d_amd import weights
@@ -301,7 +356,7 @@ def test_level0_composed_block_runs_the_dedicated_kernel(monkeypatch):
     # 9 x 3 tiles, ONE tile (every border at once), 32 x 16 tiles, and 32 x 12 tiles in segments of 4 (found by scripts/gpu_fuzz_parity.py:
     # the activation plan took the block for un-composed when the tile count was no power of two and put its output on a live buffer)
     for B, H, W, seed in ((3, 72, 96, 41), (2, 8, 32, 42), (1, 256, 512, 43), (1, 256, 384, 44)):
-        monkeypatch.setenv('TS2D_U0SEG', '4' if W == 384 else '0')
+        seg = {'u0seg': 4} if W == 384 else {}
         sd = weights.synthetic_state_dict(arch, seed)
         for k in sd:
             if 'transpconvs' in k and k.endswith('bias'):
@@ -310,24 +365,26 @@ def test_level0_composed_block_runs_the_dedicated_kernel(monkeypatch):
         x = cases.make_input(arch, B, H, W, seed)
         ref = O.unet_forward(arch, sd, x).numpy()
         out = {}
-        for tag, env in (('up0', {}), ('upc', {'TS2D_UP0': '0'}), ('two', {'TS2D_UPC': '0'})):
-            for k in ('TS2D_UP0', 'TS2D_UPC'):
-                monkeypatch.delenv(k, raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            with Engine(arch, blob) as e:
+        ref16, inter16 = O.unet_forward(arch, sd, x, return_intermediates=True, emulate='f16')
+        for tag, opt in (('up0', {}), ('upc', {'up0': 0}), ('two', {'upc': 0})):
+            with Engine(arch, blob, options=dict(seg, **opt)) as e:
                 e.set_profiling(True)
                 lg, _ = e.forward(x, logits=True)
                 kern = e.op_kernels()['dec0.c0']
                 e.set_profiling(False)
                 t = e.debug_tensor('dec0.c0')
-                lh = kh = None
+                lh = kh = th = None
                 if tag != 'two':                                # the 16-bit mode of the same two kernels
                     e.set_precision('f16')
                     e.set_profiling(True)
                     lh, _ = e.forward(x, logits=True)
                     kh = e.op_kernels()['dec0.c0']
                     e.set_profiling(False)
+                    # per-layer, against the 16-bit oracle fed with the ENGINE's own inputs of the block (nothing accumulates in front)
+                    th = e.debug_tensor('dec0.c0')
+                    o16 = O.layer_forward(arch, sd, 'dec0.c0', e.debug_tensor('dec1.c1'), e.debug_tensor('enc0.c1'), emulate='f16', storage_view=True).numpy()
+                    assert np.abs(th - o16).max() <= F16_LAYER_MAX and np.sqrt(np.mean((th - o16) ** 2)) <= F16_LAYER_RMS, \
+                        (tag, H, W, float(np.abs(th - o16).max()))
                 out[tag] = (lg, t, kern, lh, kh)
         pow2 = (W // 32) & (W // 32 - 1) == 0 and ((W // 32) * (H // 8)) & ((W // 32) * (H // 8) - 1) == 0
         assert out['up0'][2] == 'conv3x3_up0' and out['up0'][4] == 'conv3x3_up0' and out['two'][2] != 'conv3x3_up0'
@@ -337,15 +394,17 @@ def test_level0_composed_block_runs_the_dedicated_kernel(monkeypatch):
         for tag in ('upc', 'two'):
             assert np.abs(out['up0'][1] - out[tag][1]).max() <= 3e-5, (tag, H, W)
         assert np.abs(out['up0'][0] - ref).max() <= TOL
-        d16 = out['up0'][3] - out['upc'][3]                     # two fp16 pipelines that differ in summation order only
-        assert np.abs(d16).max() <= 0.05 and np.sqrt(np.mean(d16 ** 2)) <= 5e-3, (float(np.abs(d16).max()), H, W)
+        for tag in ('up0', 'upc'):                              # both 16-bit kernels against the 16-bit oracle, end to end
+            d16 = out[tag][3] - ref16.numpy()
+            assert np.abs(d16).max() <= F16E_MAX and np.sqrt(np.mean(d16 ** 2)) <= F16E_RMS, (tag, float(np.abs(d16).max()), H, W)
 
 
-def test_f16_composed_block_on_16x32_tiles(monkeypatch):
+def test_f16_composed_block_on_16x32_tiles():
     """kernels_upc_h2.h: the 16-bit composed decoder entry with four M tiles per wave (16 x 32 output tiles, skip-half weights by
-    LDS-DMA).  Must be the kernel that serves the 64-column blocks on complete 16 x 32 tiles; compared with conv3x3_upc_h
-    (TS2D_UH2=0: same arithmetic, other summation order) and the oracle, transposed-conv bias x 40 (border variants), tiles on every
-    border, one and several tiles per image, KS = 2 and 4 (128 / 64 coarse channels per barrier pair)."""
+    LDS-DMA).  Must be the kernel that serves the 64-column blocks on complete 16 x 32 tiles; both it and conv3x3_upc_h
+    (option "uh2" = 0: same arithmetic, other summation order) are compared with the 16-BIT oracle - end to end and per layer with
+    the engine's own layer inputs - transposed-conv bias x 40 (border variants), tiles on every border, one and several tiles per
+    image, KS = 2 and 4 (128 / 64 coarse channels per barrier pair)."""
     from oracle import torch_oracle as O
     from totalsegmentator2d_amd import weights
     for arch, B, H, W, seed in ((cases.unet(3, (64, 64, 128), 5, cin=1), 2, 64, 64, 51),        # levels 0 and 1 compose (KS = 4, 2 x 4 and 1 x 2 tiles)
@@ -356,21 +415,26 @@ def test_f16_composed_block_on_16x32_tiles(monkeypatch):
                 sd[k] = (sd[k] * 40.0).astype(np.float32)
         blob = weights.pack_blob(arch, sd)
         x = cases.make_input(arch, B, H, W, seed)
-        ref = O.unet_forward(arch, sd, x).numpy()
+        ref16 = O.unet_forward(arch, sd, x, emulate='f16').numpy()
         out = {}
-        for uh2 in ('1', '0'):
-            monkeypatch.setenv('TS2D_UH2', uh2)
-            monkeypatch.setenv('TS2D_H2', uh2)                  # the plain C -> C blocks of the same tiling (conv3x3_h2 = the skip phase alone)
-            with Engine(arch, blob) as e:
+        for uh2 in (1, 0):
+            # ("h2": the plain C -> C blocks of the same tiling - conv3x3_h2 = the skip phase alone)
+            with Engine(arch, blob, options={'uh2': uh2, 'h2': uh2}) as e:
                 e.set_precision('f16')
                 e.set_profiling(True)
                 lg, _ = e.forward(x, logits=True)
                 out[uh2] = (lg, e.op_kernels()['dec0.c0'], e.op_kernels()['dec0.c1'])
-        assert out['1'][1] == 'conv3x3_upc_h2' and out['0'][1] == 'conv3x3_upc_h<64>'
-        assert out['1'][2] == 'conv3x3_h2' and out['0'][2] == 'conv3x3_h32<64>'
-        d = out['1'][0] - out['0'][0]
-        assert np.abs(d).max() <= 0.05 and np.sqrt(np.mean(d ** 2)) <= 5e-3, float(np.abs(d).max())
-        assert np.abs(out['1'][0] - ref).max() <= 0.3 and np.sqrt(np.mean((out['1'][0] - ref) ** 2)) <= 0.03
+                e.set_profiling(False)
+                for name, ins in (('dec0.c0', ('dec1.c1', 'enc0.c1')), ('dec1.c0', ('enc2.c1', 'enc1.c1')), ('dec0.c1', ('dec0.c0',)), ('enc1.c1', ('enc1.c0',))):
+                    got = e.debug_tensor(name)
+                    want = O.layer_forward(arch, sd, name, *[e.debug_tensor(i) for i in ins], emulate='f16', storage_view=True).numpy()
+                    assert np.abs(got - want).max() <= F16_LAYER_MAX and np.sqrt(np.mean((got - want) ** 2)) <= F16_LAYER_RMS, \
+                        (uh2, name, float(np.abs(got - want).max()))
+        assert out[1][1] == 'conv3x3_upc_h2' and out[0][1] == 'conv3x3_upc_h<64>'
+        assert out[1][2] == 'conv3x3_h2' and out[0][2] == 'conv3x3_h32<64>'
+        for uh2 in (1, 0):
+            d = out[uh2][0] - ref16
+            assert np.abs(d).max() <= F16E_MAX and np.sqrt(np.mean(d ** 2)) <= F16E_RMS, (uh2, float(np.abs(d).max()))
 
 
 def test_randomised_shapes_against_the_torch_oracle():
@@ -391,11 +455,13 @@ def test_randomised_shapes_against_the_torch_oracle():
         sd = weights.synthetic_state_dict(arch, 300 + t)
         x = prng.normal_f32(400 + t, 1, (B, cin, H, W))
         ref = O.unet_forward(arch, sd, x).numpy()
+        ref16 = O.unet_forward(arch, sd, x, emulate='f16').numpy()
+        small = (H >> (ns - 1)) * (W >> (ns - 1)) < 16      # a bottleneck of a few pixels: InstanceNorm amplifies the fp16 roundings
         with Engine(arch, weights.pack_blob(arch, sd)) as e:
-            for mode, tol in (('split', TOL), ('exact', TOL), ('f16', 0.2)):
+            for mode, tol, want in (('split', TOL, ref), ('exact', TOL, ref), ('f16', 0.2 if small else F16E_MAX, ref if small else ref16)):
                 e.set_precision(mode)
                 lg, mk = e.forward(x, logits=True, mask=(W % 32 == 0))
-                assert np.abs(lg - ref).max() <= tol, (t, mode, feats, K, cin, B, H, W)
+                assert np.abs(lg - want).max() <= tol, (t, mode, feats, K, cin, B, H, W, float(np.abs(lg - want).max()))
                 if mk is not None:
                     assert np.array_equal(unpack_mask(mk, W), _oracle_mask(lg)), (t, mode)
 
@@ -451,7 +517,7 @@ def test_config3_full_model_set_batch128_f16():
     x = parallel.synth_slices(0, 0, 0, B, (2, 512, 512))
     seeds = {mid: i + 1 for i, mid in enumerate(sorted(TS2D_V2_HEADS))}
     merged_rows, lo = {}, 0
-    for mid in sorted(TS2D_V2_HEADS):                      # one engine alive at a time: 43 GB of workspace each at B = 128
+    for mid in sorted(TS2D_V2_HEADS):                      # one engine alive at a time (~7 GB of workspace each at B = 128 in this mode)
         arch = UNetArch.canonical(num_classes=TS2D_V2_HEADS[mid])
         sd, blob = blob_for(arch, seeds[mid])
         with SubModelSet([(mid, arch, blob)], precision='f16') as ms:
@@ -463,6 +529,8 @@ def test_config3_full_model_set_batch128_f16():
             torch.cuda.synchronize()
             assert torch.equal(mk0[0], m[0]) and torch.equal(mk77[0], m[77])            # batch independence at B = 128
             ref = O.unet_forward(arch, sd, x[:1].cpu().numpy()).numpy()
+            d16 = lg0.cpu().numpy() - O.unet_forward(arch, sd, x[:1].cpu().numpy(), emulate='f16').numpy()
+            assert np.abs(d16).max() <= F16E_MAX and np.sqrt((d16 ** 2).mean()) <= F16E_RMS, (mid, float(np.abs(d16).max()))
             d = lg0.cpu().numpy() - ref
             assert np.abs(d).max() <= F16_MAX and np.sqrt((d ** 2).mean()) <= F16_RMS
             assert (unpack_mask(mk0.cpu().numpy(), 512) != O.logits_to_mask(ref).numpy()).mean() <= F16_MASK
@@ -505,25 +573,3 @@ def test_activation_buffers_are_shared_by_liveness():
             e.keep_activations(True)
             b, mb = e.forward(x, logits=True, mask=True)
             assert np.array_equal(a, b) and np.array_equal(ma, mb), mode
-
-
-def test_opt_in_16x16x32_kernel_parity(monkeypatch):
-    """conv3x3_f16x3_qp16 (TS2D_Q16=1; kernels_f16x3_qp16.h): the persistent pipeline on v_mfma_f32_16x16x32_f16 with K packed by the
-    hi / lo parts.  Measured slower than the 32x32x16 form and therefore opt-in - but it is a complete kernel
-    and stays inside the fp32 parity tolerance, layer by layer and end to end; both experiment variants."""
-    from oracle import torch_oracle as O
-    arch, B, H, W, seed = cases.SMALL_CASES['net5_128']
-    sd, blob = blob_for(arch, seed)
-    x = cases.make_input(arch, B, H, W, seed)
-    ref, inter = O.unet_forward(arch, sd, x, return_intermediates=True)
-    monkeypatch.setenv('TS2D_Q16', '1')
-    for var in ('0', '1'):
-        monkeypatch.setenv('TS2D_Q16V', var)
-        with Engine(arch, blob) as e:
-            e.set_profiling(True)
-            lg, _ = e.forward(x)
-            kern = e.op_kernels()
-            assert kern['enc1.c1'] == 'conv3x3_f16x3_qp16' and kern['enc2.c1'] == 'conv3x3_f16x3_qp16'      # 64 ch @ 64x64, 128 ch @ 32x32
-            assert np.abs(lg - ref.numpy()).max() <= TOL
-            for n in ('enc1.c1', 'enc2.c1', 'dec1.c1'):
-                assert np.abs(e.debug_tensor(n) - inter[n].numpy()).max() <= TOL, n

@@ -56,6 +56,10 @@ def test_config1_sample_s0616_canonical_net():
     seg = (out.astype(np.float32) > 1.5 * 2.0 ** -24)
     seg_ref = O.logits_to_mask(ref).numpy().astype(bool)
     assert (seg != seg_ref).mean() < 1e-3
+    # the differing mask bits are tolerance flips: the oracle's aggregated logit lies within the logit error of the threshold
+    flips = seg != seg_ref
+    if flips.any():
+        assert np.abs(ref.astype(np.float32)[flips] - 1.5 * 2.0 ** -24).max() <= d.max()
 
 
 @pytest.mark.parametrize('order', ['float', 'half'])

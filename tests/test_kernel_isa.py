@@ -56,10 +56,10 @@ def test_upq_counted_wait_matches_the_emitted_stream(asm):
 
 
 def test_persistent_pipelines_drain_before_their_barrier(asm):
-    """conv3x3_f16x3_qp / qp16 retire EVERYTHING (vmcnt(0)) in front of the per-item barrier: every barrier that follows a
+    """conv3x3_f16x3_qp retires EVERYTHING (vmcnt(0)) in front of the per-item barrier: every barrier that follows a
     global_load_lds in those kernels must be preceded by a vmcnt wait.  (conv3x3_upq leaves the loop with one surplus DMA of the
     repeated last chunk in flight into a weight buffer nobody reads again: its epilogue barriers are LDS-only by design.)"""
-    for frag in ('conv3x3_f16x3_qpE', 'conv3x3_f16x3_qp16'):
+    for frag in ('conv3x3_f16x3_qpE',):
         body = _body(asm, frag)
         pending = False
         for i, ln in enumerate(body):
@@ -70,10 +70,10 @@ def test_persistent_pipelines_drain_before_their_barrier(asm):
                 pending = False
             elif op == 's_barrier':
                 assert not pending, f'{frag}: a barrier is reached with an un-waited LDS-DMA in flight (line {i})'
-    # register spills: a scratch reload is a VMEM operation - inside the MFMA stream it would wait for the DMA in flight.  qp16 and upq
-    # have none; conv3x3_f16x3_qp sits at the 256-register limit and may spill a few dwords whose reloads lie in the per-tile epilogue
+    # register spills: a scratch reload is a VMEM operation - inside the MFMA stream it would wait for the DMA in flight.  upq
+    # has none; conv3x3_f16x3_qp sits at the 256-register limit and may spill a few dwords whose reloads lie in the per-tile epilogue
     # (behind the last MFMA of the item), never between the MFMAs
-    for frag in ('conv3x3_f16x3_qp16', 'conv3x3_upq'):
+    for frag in ('conv3x3_upq',):
         assert not any(ln.startswith('scratch_') for ln in _body(asm, frag)), f'{frag} spills registers'
     body = _body(asm, 'conv3x3_f16x3_qpE')
     loads = [i for i, ln in enumerate(body) if ln.startswith('scratch_load')]

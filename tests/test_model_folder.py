@@ -103,3 +103,10 @@ def test_model_folder_prediction_matches_manual_initialization(tmp_path):
     finally:
         a.close(); b.close()
     assert ya.dtype == np.float16 and np.array_equal(ya, yb)
+    # ... and the folder-loaded predictor against the ORACLE (not only against a second HIP predictor): two folds, four mirror passes,
+    # float16 aggregation - the tolerance of the sliding-window goldens (2 half-ulps at |x| <= 8)
+    from oracle import torch_oracle as O
+    sds = [weights.synthetic_state_dict(arch, s) for s in (seed, seed + 1)]
+    ref = O.predict_logits(arch, sds, data, patch, step, (0, 1)).numpy()
+    assert ref.shape == ya.shape
+    assert np.abs(ya.astype(np.float32) - ref.astype(np.float32)).max() <= 1.6e-2 and (ya != ref).mean() < 0.05

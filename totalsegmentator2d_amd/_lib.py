@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libts2d_engine.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'ts2d_engine.h')
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_STAGES = 16
 PRECISION_F32_EXACT = 0
 PRECISION_F32_SPLIT_F16X3 = 1
@@ -20,7 +20,7 @@ PRECISION_F16 = 2
 
 # every symbol include/ts2d_engine.h declares
 SYMBOLS = ('ts2d_engine_create', 'ts2d_engine_load_weights', 'ts2d_engine_weight_buffer', 'ts2d_engine_weights_ready',
-           'ts2d_engine_forward', 'ts2d_engine_check', 'ts2d_engine_predict_tiled', 'ts2d_engine_tiled_inf_flag', 'ts2d_engine_set_tile_dtype', 'ts2d_engine_set_keep_activations', 'ts2d_project_coronal', 'ts2d_project_coronal_zscore', 'ts2d_synth_slices', 'ts2d_engine_reserve', 'ts2d_engine_set_precision', 'ts2d_engine_set_profiling', 'ts2d_engine_num_ops',
+           'ts2d_engine_forward', 'ts2d_engine_check', 'ts2d_engine_predict_tiled', 'ts2d_engine_tiled_inf_flag', 'ts2d_engine_set_tile_dtype', 'ts2d_engine_set_keep_activations', 'ts2d_project_coronal', 'ts2d_project_coronal_zscore', 'ts2d_synth_slices', 'ts2d_engine_reserve', 'ts2d_engine_workspace_bytes', 'ts2d_engine_set_workspace', 'ts2d_engine_set_precision', 'ts2d_engine_set_option', 'ts2d_engine_set_profiling', 'ts2d_engine_num_ops',
            'ts2d_engine_op_name', 'ts2d_engine_op_kernel', 'ts2d_engine_op_times', 'ts2d_engine_debug_tensor', 'ts2d_engine_device_bytes', 'ts2d_engine_destroy',
            'ts2d_last_error', 'ts2d_abi_version')
 
@@ -92,8 +92,14 @@ def load():
     lib.ts2d_synth_slices.argtypes = [c.c_int, c.c_ulonglong, c.c_ulonglong, c.c_ulonglong, c.c_void_p, c.c_void_p]
     lib.ts2d_engine_reserve.restype = c.c_int
     lib.ts2d_engine_reserve.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int]
+    lib.ts2d_engine_workspace_bytes.restype = c.c_int
+    lib.ts2d_engine_workspace_bytes.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_size_t)]
+    lib.ts2d_engine_set_workspace.restype = c.c_int
+    lib.ts2d_engine_set_workspace.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t]
     lib.ts2d_engine_set_precision.restype = c.c_int
     lib.ts2d_engine_set_precision.argtypes = [c.c_void_p, c.c_int]
+    lib.ts2d_engine_set_option.restype = c.c_int
+    lib.ts2d_engine_set_option.argtypes = [c.c_void_p, c.c_char_p, c.c_int]
     lib.ts2d_engine_set_tile_dtype.restype = c.c_int
     lib.ts2d_engine_set_tile_dtype.argtypes = [c.c_void_p, c.c_int]
     lib.ts2d_engine_set_keep_activations.restype = c.c_int

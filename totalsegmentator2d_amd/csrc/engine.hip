@@ -9,7 +9,6 @@
 #include "kernels_head.h"
 #include "kernels_f16x3_one.h"
 #include "kernels_f16x3_qp.h"
-#include "kernels_f16x3_qp16.h"
 #include "kernels_first.h"
 #include "kernels_res32.h"
 #include "kernels_s2v2.h"
@@ -129,25 +128,30 @@ struct ts2d_engine {
     int num_cus = 256;
     int tile_half = 0;            // sliding-window blend order (ts2d_engine_set_tile_dtype): 0 = fp32 tile (reference CPU path)
     int tiled_inf = 0;            // the last predict_tiled produced an infinite aggregated logit (ts2d_engine_tiled_inf_flag)
-    bool use_h32 = true;          // precision mode f16: 32-channel-chunk kernel (TS2D_H32=0 falls back to the 16-channel one)
-    bool use_one = true;          // one-image-tile split kernel (TS2D_ONE=0 falls back to the generic one)
-    int dbg = 0;                  // TS2D_DBG: timing ablations (diagnostic runs only)
-    bool use_s2v2 = true;         // 512-thread stride-2 kernel (TS2D_S2V2=0 falls back)
-    bool use_q = true;            // persistent 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (TS2D_Q=0 falls back to conv3x3_f16x3_one)
-    int upq_min = 256;            // TS2D_UPQ_MIN: least coarse channel count served by conv3x3_upq
-    int q16_var = 0;              // TS2D_Q16V: experiment switches of conv3x3_f16x3_qp16
-    bool use_q16 = false;         // TS2D_Q16=1: ... on v_mfma_f32_16x16x32_f16 (conv3x3_f16x3_qp16: measured 1.5-10 % slower than the 32x32x16 form, opt-in)
-    bool use_h2 = true;           // 16-bit plain C -> C blocks on 16 x 32 tiles (TS2D_H2=0: conv3x3_h32); h2_min: least channel count
+    // Kernel-dispatch options (ts2d_engine_set_option; ABI 6).  Each selects between two complete, parity-tested kernels for the ops it
+    // names; the defaults are the measured-fastest ones.  They are per-HANDLE state set through the C-ABI - the caller's environment
+    // never changes which kernel runs.
+    bool use_h32 = true;          // "h32": precision mode f16, 32-channel-chunk kernel (0: the 16-channel one)
+    bool use_one = true;          // "one": one-image-tile kernels (0: the generic ones; also switches every kernel built on them off)
+    bool use_s2v2 = true;         // "s2v2": 512-thread stride-2 kernel
+    bool use_q = true;            // "q": persistent 512-thread double-buffered stride-1 kernel on 16 x 32 tiles (0: conv3x3_f16x3_one)
+    int upq_min = 256;            // "upq_min": least coarse channel count served by conv3x3_upq
+    bool use_h2 = true;           // "h2": 16-bit plain C -> C blocks on 16 x 32 tiles (0: conv3x3_h32); "h2_min": least channel count
     int h2_min = 64;
-    bool use_uh2 = true;          // 16-bit composed block on 16 x 32 tiles (TS2D_UH2=0: conv3x3_upc_h)
-    bool use_up0 = true;          // dedicated persistent kernel of the level-0 composed block (TS2D_UP0=0: conv3x3_upc<32>)
-    bool use_upq = true;          // 512-thread double-buffered variant of the composed block on 16 x 32 tiles (TS2D_UPQ=0: conv3x3_upc)
-    bool use_upc = true;          // decoder c0 blocks composed with their transposed conv (TS2D_UPC=0 falls back to two kernels)
+    bool use_uh2 = true;          // "uh2": 16-bit composed block on 16 x 32 tiles (0: conv3x3_upc_h)
+    bool use_up0 = true;          // "up0": dedicated persistent kernel of the level-0 composed block (0: conv3x3_upc<32>)
+    int u0seg = 0;                // "u0seg": tiles per workgroup segment of conv3x3_up0 (0: chosen from the grid; tests force segments that end inside an image)
+    bool use_upq = true;          // "upq": 512-thread double-buffered variant of the composed block on 16 x 32 tiles (0: conv3x3_upc)
+    bool use_upc = true;          // "upc": decoder c0 blocks composed with their transposed conv (0: two kernels)
+    bool use_res = true;          // "res": resident-weight kernel of the 32 -> 32 blocks
+    bool use_fuse0 = true;        // "fuse0": first block recomputed inside the second (statistics-only pre-pass + conv3x3_res32 fused variant)
+    int dbg = 0;                  // TS2D_DBG (the one environment switch left): timing ablations / in-kernel phase stamps of diagnostic runs
     unsigned long long* d_prof = nullptr;     // TS2D_DBG=256: in-kernel phase counters, 8 per op (diagnostic)
     std::vector<char> fused_away; // per op of the last run: 1 = its output tensor was not materialised (composed into the next op)
-    bool use_res = true;          // resident-weight kernel of the 32 -> 32 blocks (TS2D_RES=0 falls back)
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
+    bool ws_external = false;     // d_ws is the caller's memory (ts2d_engine_set_workspace): shared by the engines of a sub-model set
+    char* d_stage = nullptr; size_t stage_bytes = 0;      // host-buffer forwards only (ensure_staging)
     int ws_precision = -1; bool ws_keep = false;      // the activation plan of the workspace was made for this mode (composition depends on it)
     bool keep_activations = false;                    // ts2d_engine_set_keep_activations: one buffer per tensor (debug access, full diagnosis)
     float* d_part = nullptr;
@@ -342,13 +346,18 @@ float f16_to_f32(uint16_t hb) {
 template <typename F>
 void parallel_for(int n, F&& f) {
     int nt = (int)std::thread::hardware_concurrency();
-    if (const char* v = getenv("TS2D_PACK_THREADS")) nt = atoi(v);
     nt = std::max(1, std::min(std::min(nt, 16), n));
     if (nt == 1) { for (int i = 0; i < n; ++i) f(i); return; }
+    // Thread creation can fail (process / thread limits of a pool box): nothing may escape through the C-ABI, and a started thread
+    // must be joined.  Thread t takes the indices t, t + nt, ...; the lanes whose thread could not start run here, serially.
     std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&, t]() { for (int i = t; i < n; i += nt) f(i); });
-    for (auto& x : th) x.join();
+    int started = 0;
+    try {
+        th.reserve(nt);
+        for (int t = 0; t < nt; ++t) { th.emplace_back([&f, t, nt, n]() { for (int i = t; i < n; i += nt) f(i); }); ++started; }
+    } catch (...) { /* fall through with `started` threads */ }
+    for (int t = started; t < nt; ++t) for (int i = t; i < n; i += nt) f(i);
+    for (auto& x : th) if (x.joinable()) x.join();
 }
 
 // PyTorch-layout blob -> packed device layouts (host staging buffer `out`, weight_floats long).
@@ -823,47 +832,77 @@ ActPlan plan_activations(const ts2d_engine* e, int B, int H, int W, bool keep) {
     return p;
 }
 
+// Layout of the activation workspace for (B, H, W) under the engine's current precision mode, options and keep flag.
+struct WsLayout { ActPlan plan; std::vector<size_t> o_sc, o_sh; size_t o_part = 0, o_pk = 0, bytes = 0; };
+
+WsLayout workspace_layout(const ts2d_engine* e, int B, int H, int W) {
+    WsLayout L;
+    L.plan = plan_activations(e, B, H, W, e->keep_activations);
+    size_t off = align_up(L.plan.bytes, 256);
+    L.o_sc.assign(e->tensors.size(), 0); L.o_sh.assign(e->tensors.size(), 0);
+    for (size_t i = 0; i < e->tensors.size(); ++i) {
+        const Tensor& t = e->tensors[i];
+        if (t.normed) {
+            L.o_sc[i] = off; off = align_up(off + (size_t)B * t.C * sizeof(float), 256);
+            L.o_sh[i] = off; off = align_up(off + (size_t)B * t.C * sizeof(float), 256);
+        }
+    }
+    L.o_part = off; off = align_up(off + part_floats_needed(e, B, H, W) * sizeof(float) + 256, 256);
+    L.o_pk = off; off = align_up(off + partial_floats_needed(e, B, H, W) * sizeof(float) + 256, 256);   // split-K partials
+    L.bytes = off;
+    return L;
+}
+
 int ensure_workspace(ts2d_engine* e, int B, int H, int W) {
     const bool keep = e->keep_activations;
     if (e->d_ws && e->wsB >= B && e->wsH == H && e->wsW == W && e->ws_precision == e->precision && e->ws_keep == keep) return TS2D_OK;
     HIP_TRY(hipSetDevice(e->device));
-    if (e->d_ws && e->wsH == H && e->wsW == W && e->wsB > B) B = e->wsB;      // same geometry, another mode: keep the larger batch capacity
-    const int K = e->arch.num_classes;
-    const ActPlan plan = plan_activations(e, B, H, W, keep);
-    size_t off = align_up(plan.bytes, 256);
-    std::vector<size_t> o_data(e->tensors.size()), o_sc(e->tensors.size()), o_sh(e->tensors.size());
-    for (size_t i = 0; i < e->tensors.size(); ++i) {
-        const Tensor& t = e->tensors[i];
-        o_data[i] = plan.off[i];
-        if (t.normed) {
-            o_sc[i] = off; off = align_up(off + (size_t)B * t.C * sizeof(float), 256);
-            o_sh[i] = off; off = align_up(off + (size_t)B * t.C * sizeof(float), 256);
-        }
-    }
-    const size_t o_part = off; off = align_up(off + part_floats_needed(e, B, H, W) * sizeof(float) + 256, 256);
-    const size_t o_pk = off; off = align_up(off + partial_floats_needed(e, B, H, W) * sizeof(float) + 256, 256);   // split-K partials
-    const size_t o_in = off; off = align_up(off + (size_t)B * e->arch.input_channels * H * W * sizeof(float), 256);
-    const size_t o_lg = off; off = align_up(off + (size_t)B * K * H * W * sizeof(float), 256);
-    const size_t o_mk = off; off = align_up(off + (size_t)B * K * H * ((W + 31) / 32) * sizeof(uint32_t), 256);
+    if (e->d_ws && e->wsH == H && e->wsW == W && e->wsB > B && !e->ws_external) B = e->wsB;      // same geometry, another mode: keep the larger batch capacity
+    const WsLayout L = workspace_layout(e, B, H, W);
     if (e->d_ws) {      // the old workspace may still be in use by a run on ANY stream: wait for its end-of-run event
         if (e->ws_busy) { HIP_TRY(hipEventSynchronize(e->ws_event)); e->ws_busy = false; }
         HIP_TRY(hipStreamSynchronize(e->stream));
-        if (e->ws_bytes < off) { HIP_TRY(hipFree(e->d_ws)); e->d_ws = nullptr; e->ws_bytes = 0; }      // (a mode change that fits re-maps the same memory)
     }
-    if (!e->d_ws) { HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_ws), off)); e->ws_bytes = off; }
+    if (e->ws_external) {      // caller-provided memory (ts2d_engine_set_workspace): never allocated or freed here
+        if (e->ws_bytes < L.bytes)
+            return fail(TS2D_ERR_NOMEM, "the workspace given to ts2d_engine_set_workspace holds %zu bytes, B=%d H=%d W=%d needs %zu "
+                        "(ts2d_engine_workspace_bytes)", e->ws_bytes, B, H, W, L.bytes);
+    } else {
+        if (e->d_ws && e->ws_bytes < L.bytes) { HIP_TRY(hipFree(e->d_ws)); e->d_ws = nullptr; e->ws_bytes = 0; }      // (a mode change that fits re-maps the same memory)
+        if (!e->d_ws) { HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_ws), L.bytes)); e->ws_bytes = L.bytes; }
+    }
     e->wsB = B; e->wsH = H; e->wsW = W; e->ws_precision = e->precision; e->ws_keep = keep;
     for (size_t i = 0; i < e->tensors.size(); ++i) {
         Tensor& t = e->tensors[i];
-        t.data = plan.used[i] ? reinterpret_cast<float*>(e->d_ws + o_data[i]) : nullptr;
-        t.resident = plan.used[i] && !plan.reused[i];
-        t.scale = t.normed ? reinterpret_cast<float*>(e->d_ws + o_sc[i]) : nullptr;
-        t.shift = t.normed ? reinterpret_cast<float*>(e->d_ws + o_sh[i]) : nullptr;
+        t.data = L.plan.used[i] ? reinterpret_cast<float*>(e->d_ws + L.plan.off[i]) : nullptr;
+        t.resident = L.plan.used[i] && !L.plan.reused[i];
+        t.scale = t.normed ? reinterpret_cast<float*>(e->d_ws + L.o_sc[i]) : nullptr;
+        t.shift = t.normed ? reinterpret_cast<float*>(e->d_ws + L.o_sh[i]) : nullptr;
     }
-    e->d_part = reinterpret_cast<float*>(e->d_ws + o_part);
-    e->d_partial = reinterpret_cast<float*>(e->d_ws + o_pk);
-    e->d_in_stage = reinterpret_cast<float*>(e->d_ws + o_in);
-    e->d_logit_stage = reinterpret_cast<float*>(e->d_ws + o_lg);
-    e->d_mask_stage = reinterpret_cast<uint32_t*>(e->d_ws + o_mk);
+    e->d_part = reinterpret_cast<float*>(e->d_ws + L.o_part);
+    e->d_partial = reinterpret_cast<float*>(e->d_ws + L.o_pk);
+    return TS2D_OK;
+}
+
+// Staging memory of the HOST-buffer forward (input, logits, masks of one batch): allocated on the first such call only - a caller
+// that passes device pointers (the bench, the multi-GPU stream, SubModelSet) never pays for it (1.3 GB at B = 64, K = 18).
+int ensure_staging(ts2d_engine* e, int B, int H, int W) {
+    const int K = e->arch.num_classes;
+    size_t off = 0;
+    const size_t o_in = off; off = align_up(off + (size_t)B * e->arch.input_channels * H * W * sizeof(float), 256);
+    const size_t o_lg = off; off = align_up(off + (size_t)B * K * H * W * sizeof(float), 256);
+    const size_t o_mk = off; off = align_up(off + (size_t)B * K * H * ((W + 31) / 32) * sizeof(uint32_t), 256);
+    if (off > e->stage_bytes) {
+        HIP_TRY(hipSetDevice(e->device));
+        if (e->ws_busy) { HIP_TRY(hipEventSynchronize(e->ws_event)); e->ws_busy = false; }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->d_stage) { HIP_TRY(hipFree(e->d_stage)); e->d_stage = nullptr; e->stage_bytes = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_stage), off));
+        e->stage_bytes = off;
+    }
+    e->d_in_stage = reinterpret_cast<float*>(e->d_stage + o_in);
+    e->d_logit_stage = reinterpret_cast<float*>(e->d_stage + o_lg);
+    e->d_mask_stage = reinterpret_cast<uint32_t*>(e->d_stage + o_mk);
     return TS2D_OK;
 }
 
@@ -945,7 +984,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
     e->n_launched = 0;
     e->fused_away.assign(e->ops.size(), 0);
     // (the input is scanned by ts2d_engine_check only when it lives in the engine's own staging memory)
-    e->last_input = (d_in == e->d_in_stage || (e->d_sw && reinterpret_cast<const char*>(d_in) >= e->d_sw &&
+    e->last_input = ((e->d_in_stage && d_in == e->d_in_stage) || (e->d_sw && reinterpret_cast<const char*>(d_in) >= e->d_sw &&
                                                reinterpret_cast<const char*>(d_in) < e->d_sw + e->sw_bytes)) ? d_in : nullptr;
     e->lastB = B; e->lastH = H; e->lastW = W; e->last_stream = st;
     const bool f16 = e->precision == TS2D_PRECISION_F16;      // fp16 storage, one fp16 MFMA product, fp32 accumulate/statistics
@@ -1039,7 +1078,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 const int tpi0 = u0.tiles_x * u0.tiles_y, want = std::min(u0.n_tiles, 2 * e->num_cus);
                 int seg = 1;          // (segments as conv3x3_res32: the largest divisor of an image's tiles that leaves >= 2 workgroups per CU)
                 for (int d = 1; d <= tpi0; ++d) if (tpi0 % d == 0 && u0.n_tiles / d >= want) seg = d;
-                if (getenv("TS2D_U0SEG") && atoi(getenv("TS2D_U0SEG")) > 0 && tpi0 % atoi(getenv("TS2D_U0SEG")) == 0) seg = atoi(getenv("TS2D_U0SEG"));      // (test switch)
+                if (e->u0seg > 0 && tpi0 % e->u0seg == 0) seg = e->u0seg;      // (option "u0seg": tests)
                 u0.seg = seg;
                 TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_up0");
                 if (f16) {
@@ -1261,19 +1300,10 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 ca.lg_tx = lg_exact(ca.tiles_x); ca.lg_tpi = lg_exact(ca.tiles_x * ca.tiles_y);
                 const int gridq = (ca.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
                 const int gridp = std::min(gridq, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));     // one persistent workgroup per CU
-                if (e->use_q16) {
-#define TS2D_Q16_LAUNCH(V_) do { static std::atomic<uint64_t> done_{0}; \
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp16<V_>), done_)); \
-                    hipLaunchKernelGGL(conv3x3_f16x3_qp16<V_>, dim3(gridp), dim3(kQThreads), kQ16Lds, st, ca); } while (0)
-                    if (e->q16_var & 1) TS2D_Q16_LAUNCH(1); else TS2D_Q16_LAUNCH(0);
-#undef TS2D_Q16_LAUNCH
-                    le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp16");
-                } else {
-                    static std::atomic<uint64_t> doneqp{0};
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp), doneqp));
-                    hipLaunchKernelGGL(conv3x3_f16x3_qp, dim3(gridp), dim3(kQThreads), kQpLds, st, ca);
-                    le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp");
-                }
+                static std::atomic<uint64_t> doneqp{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp), doneqp));
+                hipLaunchKernelGGL(conv3x3_f16x3_qp, dim3(gridp), dim3(kQThreads), kQpLds, st, ca);
+                le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp");
             } else if (one) {     // tile inside one image: lean staging path
                 le = launch_one(bn, ca, grid, smem, st); prof_kernel(e, bn == 64 ? "conv3x3_f16x3_one<64>" : "conv3x3_f16x3_one<32>");
             } else if (one_s2) {
@@ -1349,7 +1379,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
 // ------------------------------------------------------------------------------------------------- C-ABI
 extern "C" {
 
-int ts2d_abi_version(void) { return 5; }
+int ts2d_abi_version(void) { return 6; }
 
 const char* ts2d_last_error(void) { return g_err.c_str(); }
 
@@ -1365,20 +1395,6 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
-        if (getenv("TS2D_H32")) e->use_h32 = getenv("TS2D_H32")[0] == '1';
-        if (getenv("TS2D_ONE")) e->use_one = getenv("TS2D_ONE")[0] == '1';
-        if (getenv("TS2D_RES")) e->use_res = getenv("TS2D_RES")[0] == '1';
-        if (getenv("TS2D_S2V2")) e->use_s2v2 = getenv("TS2D_S2V2")[0] == '1';
-        if (getenv("TS2D_Q")) e->use_q = getenv("TS2D_Q")[0] == '1';
-        if (getenv("TS2D_Q16")) e->use_q16 = getenv("TS2D_Q16")[0] == '1';
-        if (getenv("TS2D_Q16V")) e->q16_var = atoi(getenv("TS2D_Q16V"));
-        if (getenv("TS2D_UPQ_MIN")) e->upq_min = atoi(getenv("TS2D_UPQ_MIN"));
-        if (getenv("TS2D_UPQ")) e->use_upq = getenv("TS2D_UPQ")[0] == '1';
-        if (getenv("TS2D_UP0")) e->use_up0 = getenv("TS2D_UP0")[0] == '1';
-        if (getenv("TS2D_UH2")) e->use_uh2 = getenv("TS2D_UH2")[0] == '1';
-        if (getenv("TS2D_H2")) e->use_h2 = getenv("TS2D_H2")[0] == '1';
-        if (getenv("TS2D_H2_MIN")) e->h2_min = atoi(getenv("TS2D_H2_MIN"));
-        if (getenv("TS2D_UPC")) e->use_upc = getenv("TS2D_UPC")[0] == '1';
         if (getenv("TS2D_DBG")) e->dbg = atoi(getenv("TS2D_DBG"));
     }
     int rc = build_program(e);
@@ -1426,6 +1442,24 @@ int ts2d_engine_set_precision(ts2d_engine* e, int mode) {
     return TS2D_OK;
 }
 
+int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
+    if (!e || !name) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_option: null argument");
+    struct B { const char* n; bool* p; };
+    struct I { const char* n; int* p; int lo, hi; };
+    const B bools[] = {{"h32", &e->use_h32}, {"one", &e->use_one}, {"s2v2", &e->use_s2v2}, {"q", &e->use_q}, {"h2", &e->use_h2}, {"uh2", &e->use_uh2},
+                       {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}};
+    const I ints[] = {{"upq_min", &e->upq_min, 0, 1 << 20}, {"h2_min", &e->h2_min, 0, 1 << 20}, {"u0seg", &e->u0seg, 0, 1 << 20}};
+    bool found = false;
+    for (const B& b : bools) if (!strcmp(name, b.n)) { *b.p = value != 0; found = true; }
+    for (const I& i : ints) if (!strcmp(name, i.n)) {
+        if (value < i.lo || value > i.hi) return fail(TS2D_ERR_INVALID, "option %s = %d out of range [%d, %d]", name, value, i.lo, i.hi);
+        *i.p = value; found = true;
+    }
+    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0)", name);
+    e->ws_precision = -1;         // which ops compose (and with it the activation plan) depends on the options: re-plan at the next reserve / forward
+    return TS2D_OK;
+}
+
 int ts2d_engine_set_keep_activations(ts2d_engine* e, int enable) {
     if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_keep_activations: null engine");
     e->keep_activations = enable != 0;          // takes effect at the next reserve / forward (the workspace is re-planned)
@@ -1456,6 +1490,29 @@ int ts2d_engine_reserve(ts2d_engine* e, int B, int H, int W) {
     return ensure_workspace(e, B, H, W);
 }
 
+int ts2d_engine_workspace_bytes(ts2d_engine* e, int B, int H, int W, size_t* n_bytes) {
+    if (!e || !n_bytes) return fail(TS2D_ERR_INVALID, "ts2d_engine_workspace_bytes: null argument");
+    const int div = 1 << (e->arch.n_stages - 1);
+    if (B < 1 || H < div || W < div || H % div || W % div)
+        return fail(TS2D_ERR_INVALID, "shape B=%d H=%d W=%d: H and W must be positive multiples of %d", B, H, W, div);
+    *n_bytes = workspace_layout(e, B, H, W).bytes;
+    return TS2D_OK;
+}
+
+int ts2d_engine_set_workspace(ts2d_engine* e, void* dev_ptr, size_t n_bytes) {
+    if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_workspace: null engine");
+    if (dev_ptr && (reinterpret_cast<uintptr_t>(dev_ptr) & 255)) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_workspace: the pointer must be 256-byte aligned");
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->ws_busy) { HIP_TRY(hipEventSynchronize(e->ws_event)); e->ws_busy = false; }      // a run may still use the old memory
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->d_ws && !e->ws_external) HIP_TRY(hipFree(e->d_ws));
+    e->d_ws = reinterpret_cast<char*>(dev_ptr); e->ws_bytes = dev_ptr ? n_bytes : 0; e->ws_external = dev_ptr != nullptr;
+    e->ws_precision = -1; e->wsB = 0;           // re-plan inside the new memory at the next reserve / forward
+    for (Tensor& t : e->tensors) { t.data = nullptr; t.resident = false; }
+    e->lastB = 0;
+    return TS2D_OK;
+}
+
 int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W, float* logits, uint32_t* mask_packed,
                         int on_device, void* stream) {
     if (!e || !input) return fail(TS2D_ERR_INVALID, "ts2d_engine_forward: null argument");
@@ -1467,7 +1524,8 @@ int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W,
     hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
     const int K = e->arch.num_classes;
     if (on_device) return run_forward(e, input, B, H, W, logits, mask_packed, st);
-    // host buffers: staged through the workspace, synchronous
+    // host buffers: staged on the device, synchronous
+    TRY(ensure_staging(e, B, H, W));
     HIP_TRY(hipMemcpyAsync(e->d_in_stage, input, (size_t)B * e->arch.input_channels * H * W * sizeof(float), hipMemcpyHostToDevice, st));
     TRY(run_forward(e, e->d_in_stage, B, H, W, logits ? e->d_logit_stage : nullptr, mask_packed ? e->d_mask_stage : nullptr, st));
     if (logits) HIP_TRY(hipMemcpyAsync(logits, e->d_logit_stage, (size_t)B * K * H * W * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1566,7 +1624,7 @@ int ts2d_engine_check(ts2d_engine* e) {
     // (only the LAST batch of the call is still resident: after a multi-chunk ts2d_engine_predict_tiled an earlier chunk's inf / NaN
     //  is reported, but located only if the last chunk shows it too)
     std::string where = "the head (or an earlier batch of the same call: the diagnosis sees the last batch only)";
-    bool input_bad = false;
+    bool input_bad = false, named = false;
     if (e->last_input && has_nonfinite(e->last_input, (size_t)B * e->arch.input_channels * H * W, false) == 1) { where = "the network input"; input_bad = true; }
     float* d_copy = nullptr;
     const bool was_keep = e->keep_activations;
@@ -1594,10 +1652,23 @@ int ts2d_engine_check(ts2d_engine* e) {
             const size_t n = (size_t)B * (H >> t.level) * (W >> t.level) * t.C;
             const int f = has_nonfinite(t.data, n, e->last_f16);
             const int g = (f == 0 && t.normed) ? has_nonfinite(t.scale, (size_t)B * t.C, false) : 0;
-            if (f == 1 || g == 1) { where = "layer " + op.name + (f == 1 ? "" : " (InstanceNorm statistics)"); break; }
+            if (f == 1 || g == 1) { where = "layer " + op.name + (f == 1 ? "" : " (InstanceNorm statistics)"); named = true; break; }
         }
-    if (d_copy) (void)hipFree(d_copy);
+    if (d_copy) {
+        (void)hipFree(d_copy);
+        // the diagnostic re-run grew the workspace to one buffer per tensor (~3x): give it back, the next forward re-plans the shared arena
+        if (e->ws_busy) { (void)hipEventSynchronize(e->ws_event); e->ws_busy = false; }
+        if (e->d_ws && !e->ws_external) { (void)hipFree(e->d_ws); e->d_ws = nullptr; e->ws_bytes = 0; }
+        e->ws_precision = -1;     // (re-plan at the next forward)
+        for (Tensor& t : e->tensors) { t.data = nullptr; t.resident = false; }
+        e->lastB = 0;             // (nothing of that run is readable any more)
+    }
     e->keep_activations = was_keep;
+    if (named && !was_keep && !d_copy)
+        // asynchronous device-pointer call: the input is the caller's, no re-run with private buffers was possible, and most
+        // activations of the run have been recycled - the tensor named below is only the first SURVIVING one
+        return fail(TS2D_ERR_INVALID, "non-finite logits: first surviving tensor with inf / NaN: %s (earlier activations were recycled; call "
+                    "ts2d_engine_set_keep_activations(e, 1) and re-run to localise)%s", where.c_str(), "");
     return fail(TS2D_ERR_INVALID, "non-finite logits: inf / NaN first appears in %s%s", where.c_str(),
                 e->precision == TS2D_PRECISION_F32_EXACT ? "" :
                 " (the fp16 products of this precision mode need |activation| < 65504 at every conv input: "
@@ -1746,7 +1817,7 @@ int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_
     for (size_t oi = 0; oi < e->ops.size() && oi < e->fused_away.size(); ++oi)
         if (e->fused_away[oi] && e->ops[oi].dst == ti)
             return fail(TS2D_ERR_INVALID, "tensor '%s' was not materialised by the last run: the transposed conv is composed into the next block "
-                        "(set TS2D_UPC=0 before creating the engine to run it as its own kernel)", name);
+                        "(ts2d_engine_set_option(e, \"upc\", 0) runs it as its own kernel)", name);
     const int B = e->lastB, h = e->lastH >> t.level, w = e->lastW >> t.level, C = t.C;
     dims[0] = B; dims[1] = C; dims[2] = h; dims[3] = w;
     const size_t n = (size_t)B * C * h * w;
@@ -1776,7 +1847,9 @@ int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_
     return TS2D_OK;
 }
 
-size_t ts2d_engine_device_bytes(ts2d_engine* e) { return e ? e->weight_floats * sizeof(float) + e->ws_bytes + e->sw_bytes : 0; }
+size_t ts2d_engine_device_bytes(ts2d_engine* e) {
+    return e ? e->weight_floats * sizeof(float) + (e->ws_external ? 0 : e->ws_bytes) + e->stage_bytes + e->sw_bytes : 0;
+}
 
 int ts2d_engine_destroy(ts2d_engine* e) {
     if (!e) return TS2D_OK;
@@ -1785,7 +1858,8 @@ int ts2d_engine_destroy(ts2d_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->ws_event) (void)hipEventDestroy(e->ws_event);
     for (Launch& l : e->launches) { if (l.e0) (void)hipEventDestroy(l.e0); if (l.e1) (void)hipEventDestroy(l.e1); }
-    if (e->d_ws) (void)hipFree(e->d_ws);
+    if (e->d_ws && !e->ws_external) (void)hipFree(e->d_ws);
+    if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->d_flags) (void)hipFree(e->d_flags);
     if (e->d_prof) (void)hipFree(e->d_prof);
     if (e->d_sw) (void)hipFree(e->d_sw);

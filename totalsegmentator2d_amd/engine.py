@@ -8,6 +8,7 @@ tensors are consumed zero-copy through their ``data_ptr()``.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -35,13 +36,16 @@ def _is_torch(x) -> bool:
 
 
 class Engine:
-    def __init__(self, arch: UNetArch, blob: Optional[np.ndarray], device: int = 0):
-        """blob: fp32 weight blob (:func:`weights.pack_blob`) or None for a replica to be filled by broadcast."""
+    def __init__(self, arch: UNetArch, blob: Optional[np.ndarray], device: int = 0, options: Optional[Dict[str, int]] = None):
+        """blob: fp32 weight blob (:func:`weights.pack_blob`) or None for a replica to be filled by broadcast.
+        options: kernel-dispatch options (:meth:`set_option`), e.g. ``{'upc': 0}`` - tests and A/B scripts."""
         self.lib = _lib.load()
         self.arch = arch
         self.device = int(device)
-        self._keep = False           # one buffer per activation (debug access); default: buffers shared by liveness
-        self._last = None            # arguments of the last forward (debug_tensor re-runs it with private buffers)
+        self._keep = False           # one buffer per activation: switched on by the USER (keep_activations)
+        self._auto_keep = False      # ... or by debug_tensor, until the next forward (which returns to the shared arena)
+        self._last = None            # (weak reference to the input, logits?, mask?) of the last forward: debug_tensor re-runs it with
+                                     # private buffers.  Weak: a production call must not pin the caller's batch in HBM.
         self._h = ctypes.c_void_p()
         d = _desc(arch)
         if blob is not None:
@@ -51,6 +55,8 @@ class Engine:
         else:
             _lib.check(self.lib.ts2d_engine_create(ctypes.byref(d), None, 0, self.device, ctypes.byref(self._h)),
                        'ts2d_engine_create')
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -90,6 +96,11 @@ class Engine:
         m = {'exact': _lib.PRECISION_F32_EXACT, 'split': _lib.PRECISION_F32_SPLIT_F16X3, 'f16': _lib.PRECISION_F16}.get(mode, mode)
         _lib.check(self.lib.ts2d_engine_set_precision(self._h, int(m)), 'ts2d_engine_set_precision')
 
+    def set_option(self, name: str, value: int):
+        """Kernel-dispatch option of this handle (C-ABI ts2d_engine_set_option, include/ts2d_engine.h lists the names): picks
+        between two parity-tested kernels for the ops it names; takes effect at the next forward."""
+        _lib.check(self.lib.ts2d_engine_set_option(self._h, name.encode(), int(value)), f'ts2d_engine_set_option({name})')
+
     def set_tile_dtype(self, mode):
         """Blend order of :meth:`predict_tiled`: 'float' (reference CPU path: fp32 tile, one rounding into the half buffer;
         the default) or 'half' (CUDA autocast path: half tile, half product, half sum)."""
@@ -101,16 +112,35 @@ class Engine:
         intermediate tensors back with :meth:`debug_tensor` (which switches it on itself and re-runs the last forward)."""
         _lib.check(self.lib.ts2d_engine_set_keep_activations(self._h, int(bool(on))), 'ts2d_engine_set_keep_activations')
         self._keep = bool(on)
+        self._auto_keep = False
 
     # ------------------------------------------------------------------ forward
     def reserve(self, B: int, H: int, W: int):
         _lib.check(self.lib.ts2d_engine_reserve(self._h, B, H, W), 'ts2d_engine_reserve')
 
-    def forward(self, x, logits=True, mask=False, out_logits=None, out_mask=None, stream: int = 0):
+    def workspace_bytes(self, B: int, H: int, W: int) -> int:
+        """Bytes of activation workspace :meth:`reserve` would allocate for (B, H, W) in the current precision mode."""
+        n = ctypes.c_size_t()
+        _lib.check(self.lib.ts2d_engine_workspace_bytes(self._h, B, H, W, ctypes.byref(n)), 'ts2d_engine_workspace_bytes')
+        return int(n.value)
+
+    def set_workspace(self, dev_ptr: Optional[int], n_bytes: int = 0):
+        """Run inside caller-owned device memory (C-ABI ts2d_engine_set_workspace; None: back to the engine's own allocation).
+        Engines sharing one workspace must be driven on one stream."""
+        _lib.check(self.lib.ts2d_engine_set_workspace(self._h, ctypes.c_void_p(dev_ptr) if dev_ptr else None, int(n_bytes)),
+                   'ts2d_engine_set_workspace')
+
+    def forward(self, x, logits=True, mask=False, out_logits=None, out_mask=None, stream: int = 0, _debug_rerun: bool = False):
         """x: [B,C,H,W] fp32, numpy (host) or torch CUDA tensor (device, zero-copy).
         Returns (logits or None, packed mask or None) of the same kind as x."""
         K = self.arch.num_classes
-        self._last = (x, logits, mask)
+        if self._auto_keep and not _debug_rerun:      # debug_tensor left private buffers behind: a production call returns to the shared arena
+            _lib.check(self.lib.ts2d_engine_set_keep_activations(self._h, 0), 'ts2d_engine_set_keep_activations')
+            self._auto_keep = False
+        try:
+            self._last = (weakref.ref(x), logits, mask)
+        except TypeError:
+            self._last = None
         if _is_torch(x):
             import torch
             if not x.is_cuda:
@@ -216,14 +246,17 @@ class Engine:
     def debug_tensor(self, name: str, capacity: int = 1 << 26) -> np.ndarray:
         """Test accessor: activation `name` of the last forward as torch would hold it (NCHW, norm+act applied).  Activations
         share buffers by liveness: the first call switches the engine to private buffers and runs the last forward again."""
-        if not self._keep:
-            self.keep_activations(True)
-            if self._last is not None:
-                x, lg, mk = self._last
-                self.forward(x, logits=lg, mask=mk)
-                if _is_torch(x):
-                    import torch
-                    torch.cuda.synchronize(x.device)
+        if not (self._keep or self._auto_keep):
+            x = self._last[0]() if self._last is not None else None
+            if x is None:
+                raise RuntimeError("debug_tensor: the input of the last forward is gone (the engine holds it weakly) - keep a "
+                                   "reference to it, or call keep_activations(True) before the forward")
+            _lib.check(self.lib.ts2d_engine_set_keep_activations(self._h, 1), 'ts2d_engine_set_keep_activations')
+            self._auto_keep = True
+            self.forward(x, logits=self._last[1], mask=self._last[2], _debug_rerun=True)
+            if _is_torch(x):
+                import torch
+                torch.cuda.synchronize(x.device)
         out = np.empty(capacity, dtype=np.float32)
         dims = (ctypes.c_int32 * 4)()
         _lib.check(self.lib.ts2d_engine_debug_tensor(self._h, name.encode(), out.ctypes.data, out.size, ctypes.byref(dims)),

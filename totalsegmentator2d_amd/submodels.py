@@ -27,6 +27,7 @@ class SubModelSet:
             self.ids.append(mid)
             self.engines.append(e)
         self.channels = [e.arch.num_classes for e in self.engines]
+        self._ws = None              # ONE activation workspace for all engines (they run one after the other on one stream)
 
     @property
     def num_labels(self) -> int:
@@ -38,14 +39,29 @@ class SubModelSet:
         return lo, lo + self.channels[i]
 
     def reserve(self, B: int, H: int, W: int):
+        """One workspace of the largest engine's size, shared by all sub-models (the reference drives them sequentially,
+        ``ts2d/tool.py:110-112``; here they follow each other on one stream): 1x instead of 5x the activation memory."""
+        import torch
+        need = max(e.workspace_bytes(B, H, W) for e in self.engines)
+        if self._ws is None or self._ws.numel() < need:
+            for e in self.engines:
+                e.set_workspace(None)
+            self._ws = None
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=torch.device('cuda', self.engines[0].device))
+        base = (self._ws.data_ptr() + 255) // 256 * 256
         for e in self.engines:
+            e.set_workspace(base, self._ws.numel() - (base - self._ws.data_ptr()))
             e.reserve(B, H, W)
+        self._reserved = (B, H, W)
 
     def forward_masks(self, x, out_masks: Optional[list] = None, stream: int = 0) -> list:
         """x: torch CUDA [B,C,H,W].  Runs every sub-model on the batch; returns the per-model packed masks
         [B, K_i, H, W/32] (int32) in sorted-id order (pass `out_masks` to reuse buffers)."""
         import torch
         B, _, H, W = x.shape
+        r = getattr(self, '_reserved', None)
+        if r is None or r[0] < B or r[1:] != (H, W):
+            self.reserve(B, H, W)
         if out_masks is None:
             out_masks = [torch.empty((B, k, H, W // 32), dtype=torch.int32, device=x.device) for k in self.channels]
         for e, m in zip(self.engines, out_masks):
@@ -62,6 +78,7 @@ class SubModelSet:
         for e in self.engines:
             e.close()
         self.engines = []
+        self._ws = None
 
     def __enter__(self):
         return self
