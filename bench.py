@@ -532,7 +532,7 @@ def main():
                     x1, l1, m1 = x[:1].cpu().numpy(), logits[:1].cpu().numpy(), mask[:1].cpu().numpy()
                     e16, fl16, b16, w16_, tol16 = oracle_check(arch, sd, x1, l1, m1, emulate='f16')
                     e32, *_ = oracle_check(arch, sd, x1, l1, None)
-                    out['f16_mode']['logit_max_abs_err_vs_f16_oracle'] = {'value': e16[0], 'tol': 2.5e-2, 'slices_checked': 1,
+                    out['f16_mode']['logit_max_abs_err_vs_f16_oracle'] = {'value': e16[0], 'tol': 0.1, 'slices_checked': 1,
                                                                          'mask_bits_differing': fl16, 'mask_bits_checked': b16,
                                                                          'flips_all_within_logit_error_of_threshold': tol16}
                     out['f16_mode']['logit_max_abs_err_vs_fp32_oracle'] = e32[0]

@@ -61,13 +61,14 @@ def test_logits_and_masks_match_goldens(name):
             if name != 'tiny_b37':                                                   # ... and every one of them within the logit error of the threshold
                 assert_flips_are_tolerance_flips(lg, g['logits'], unpack_mask(mk, W), unpack_mask(g['mask_packed'], W))
         inter = [k for k in g.files if k.startswith('inter/')]
-        composed = [k for k in inter if k.endswith('.up') and not e.materialised(k[6:])]   # K5 composed into K6 (kernels_upc.h)
+        # K5 composed into K6 (kernels_upc.h); the first block recomputed inside the second (conv3x3_res32<.., FUSE>): not materialised
+        composed = [k for k in inter if (k.endswith('.up') or k == 'inter/enc0.c0') and not e.materialised(k[6:])]
         for k in inter:                                                               # per-kernel parity K1..K7
             if k not in composed:
                 t = e.debug_tensor(k[6:])
                 assert t.shape == g[k].shape and np.abs(t - g[k]).max() <= TOL, k
-    if composed:                                                                      # K5 on its own kernel: two-kernel path
-        with Engine(arch, blob, options={'upc': 0}) as e:
+    if composed:                                                                      # K5 / the first block on their own kernels
+        with Engine(arch, blob, options={'upc': 0, 'fuse0': 0}) as e:
             lg0, _ = e.forward(x, logits=True)
             for k in inter:
                 t = e.debug_tensor(k[6:])
@@ -215,8 +216,19 @@ def test_config5_tsxr_geometry_9_stages_1024():
 #      (scripts/gpu_f16_oracle_err.py, numbers in DESIGN.md section 4): the bounds below are ~2x the worst case seen.
 #  (b) the fp32 oracle: how far the MODE is from fp32 (canonical net 7e-2 max / 8e-3 rms, 0.25 % of the mask bits) - a property of
 #      16-bit arithmetic, kept as a loose sanity bound only.
+# Measured (gpurun_out r4_f16cal2, canonical nets): end to end 3.2e-2 ... 4.6e-2 max / 4.2e-3 ... 5.4e-3 rms - two CORRECT fp16 pipelines
+# drift apart through 38 layers of rounding flips almost as far as either is from fp32 (6e-2 ... 9e-2 / 7e-3 ... 1e-2), so the end-to-end
+# bound can only be ~1.5x tighter than (b).  The sharp check is per layer: a plain block 3e-3 ... 5e-3 max (single fp16 flips of stored
+# values) / 3.5e-5 ... 4.6e-5 rms; a composed decoder entry 3.4e-3 ... 4.9e-3 max / 2.8e-4 ... 3.2e-4 rms (its weights are composed in fp64
+# and rounded once, the oracle rounds the transposed conv's weights, its output and the 3x3 weights).
 F16E_MAX, F16E_RMS = 0.1, 0.012                # (a) end to end, logits
-F16_LAYER_MAX, F16_LAYER_RMS = 1.5e-2, 4e-4    # (a) ONE block, fed with the engine's own inputs of that block
+F16_LAYER_MAX, F16_LAYER_RMS, F16_LAYER_RMS_COMPOSED = 1e-2, 1e-4, 7e-4    # (a) ONE block, fed with the engine's own inputs of that block
+
+
+def _f16_layer_ok(name, got, want):
+    d = np.asarray(got, np.float64) - np.asarray(want, np.float64)
+    rms_tol = F16_LAYER_RMS_COMPOSED if (name.startswith('dec') and name.endswith('.c0')) else F16_LAYER_RMS
+    return float(np.abs(d).max()) <= F16_LAYER_MAX and float(np.sqrt((d ** 2).mean())) <= rms_tol
 F16_MAX, F16_RMS, F16_MASK = 0.15, 0.02, 0.01  # (b)
 
 
@@ -246,13 +258,14 @@ def test_f16_mode_small_cases(name):
                     ins = (prog[n.replace('.c0', '.up')]['src'], o['skip'])
                 else:
                     ins = (o['src'],)
-                srcs = [x if i == 'input' else e.debug_tensor(i) for i in ins]
+                if n == 'enc0.c0' and not e.materialised(n):      # recomputed inside enc0.c1 (checked there, against the oracle's own enc0.c0)
+                    continue
+                srcs = [x if i == 'input' else (e.debug_tensor(i) if e.materialised(i) else inter16[i].numpy()) for i in ins]
                 got = e.debug_tensor(n)
                 want = O.layer_forward(arch, sd, n, *srcs, emulate='f16', storage_view=True).numpy()
                 lvl_px = got.shape[2] * got.shape[3]
                 if lvl_px >= 64:                            # (below: statistics over a handful of pixels)
-                    assert np.abs(got - want).max() <= F16_LAYER_MAX and np.sqrt(np.mean((got - want) ** 2)) <= F16_LAYER_RMS, \
-                        (n, float(np.abs(got - want).max()))
+                    assert _f16_layer_ok(n, got, want), (n, float(np.abs(got - want).max()), float(np.sqrt(np.mean((got - want) ** 2))))
             want = O.layer_forward(arch, sd, 'head', e.debug_tensor(prog['head']['src']), emulate='f16').numpy()
             assert np.abs(lg - want).max() <= F16_LAYER_MAX
         e.set_precision('split')                                                    # modes can be switched on a live engine
@@ -288,9 +301,10 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels():
     _, blob = blob_for(arch, seed)
     x = cases.make_input(arch, B, H, W, seed)
     names = ['enc0.c0', 'enc0.c1', 'enc1.c0', 'enc2.c1', 'enc4.c1', 'dec3.c0', 'dec1.c1', 'dec0.c0', 'dec0.c1']
-    with Engine(arch, blob) as e:                          # default path: includes the resident-weight 32 -> 32 kernel
+    with Engine(arch, blob) as e:                          # default path: includes the resident-weight 32 -> 32 kernel (with the first block fused in)
         lgr, _ = e.forward(x, logits=True)
-        tr = {n: e.debug_tensor(n) for n in names}
+        assert not e.materialised('enc0.c0')
+        tr = {n: e.debug_tensor(n) for n in names if n != 'enc0.c0'}
     # (conv3x3_res32, conv3x3s2_v2 and conv3x3_upc sum in another order: compared by value below;
     #  conv3x3_f16x3_qp: same conv outputs, statistics summed over other tiles)
     off = {'res': 0, 's2v2': 0, 'upc': 0, 'q': 0, 'fuse0': 0}
@@ -305,7 +319,7 @@ def test_one_image_kernels_are_bit_identical_to_the_generic_kernels():
     assert np.abs(lg0 - lg1).max() <= 1e-5
     # conv3x3_res32 (one 288-term accumulation per output instead of two 144-term chunks), conv3x3s2_v2 (16-channel chunks,
     # one tap per k-step) and conv3x3_upc (transposed conv composed into the block): same values to fp32 rounding
-    for n in names:
+    for n in tr:
         assert np.abs(tr[n] - t1[n]).max() <= 2e-5, n
     assert np.abs(lgr - lg1).max() <= 2e-5
 
@@ -383,8 +397,7 @@ def test_level0_composed_block_runs_the_dedicated_kernel():
                     # per-layer, against the 16-bit oracle fed with the ENGINE's own inputs of the block (nothing accumulates in front)
                     th = e.debug_tensor('dec0.c0')
                     o16 = O.layer_forward(arch, sd, 'dec0.c0', e.debug_tensor('dec1.c1'), e.debug_tensor('enc0.c1'), emulate='f16', storage_view=True).numpy()
-                    assert np.abs(th - o16).max() <= F16_LAYER_MAX and np.sqrt(np.mean((th - o16) ** 2)) <= F16_LAYER_RMS, \
-                        (tag, H, W, float(np.abs(th - o16).max()))
+                    assert _f16_layer_ok('dec0.c0', th, o16), (tag, H, W, float(np.abs(th - o16).max()), float(np.sqrt(np.mean((th - o16) ** 2))))
                 out[tag] = (lg, t, kern, lh, kh)
         pow2 = (W // 32) & (W // 32 - 1) == 0 and ((W // 32) * (H // 8)) & ((W // 32) * (H // 8) - 1) == 0
         assert out['up0'][2] == 'conv3x3_up0' and out['up0'][4] == 'conv3x3_up0' and out['two'][2] != 'conv3x3_up0'
@@ -428,8 +441,7 @@ def test_f16_composed_block_on_16x32_tiles():
                 for name, ins in (('dec0.c0', ('dec1.c1', 'enc0.c1')), ('dec1.c0', ('enc2.c1', 'enc1.c1')), ('dec0.c1', ('dec0.c0',)), ('enc1.c1', ('enc1.c0',))):
                     got = e.debug_tensor(name)
                     want = O.layer_forward(arch, sd, name, *[e.debug_tensor(i) for i in ins], emulate='f16', storage_view=True).numpy()
-                    assert np.abs(got - want).max() <= F16_LAYER_MAX and np.sqrt(np.mean((got - want) ** 2)) <= F16_LAYER_RMS, \
-                        (uh2, name, float(np.abs(got - want).max()))
+                    assert _f16_layer_ok(name, got, want), (uh2, name, float(np.abs(got - want).max()), float(np.sqrt(np.mean((got - want) ** 2))))
         assert out[1][1] == 'conv3x3_upc_h2' and out[0][1] == 'conv3x3_upc_h<64>'
         assert out[1][2] == 'conv3x3_h2' and out[0][2] == 'conv3x3_h32<64>'
         for uh2 in (1, 0):

@@ -763,6 +763,7 @@ size_t part_floats_needed(const ts2d_engine* e, int B, int H, int W) {
 }
 
 bool upc_applies(const ts2d_engine* e, const Op& op, int B, int H, int W);
+bool fuse0_applies(const ts2d_engine* e, int H, int W);
 
 // Activation plan (round 3): liveness-based reuse.  An activation lives from the op that writes it to the last op that reads it
 // (the encoder skips until their decoder block); its bytes then return to a first-fit free list inside ONE arena, sized by
@@ -778,8 +779,10 @@ ActPlan plan_activations(const ts2d_engine* e, int B, int H, int W, bool keep) {
     // which ops run, what they read
     std::vector<char> skipped(no, 0);
     std::vector<std::vector<int>> reads(no);
+    const bool fused0 = fuse0_applies(e, H, W);            // first block recomputed inside the second: its output tensor is never materialised
     for (size_t i = 0; i < no; ++i) {
         const Op& op = e->ops[i];
+        if (fused0 && i == 1) continue;                    // (reads the network input, which is not part of the arena)
         if (op.type == OP_CONVT && i + 1 < no && e->ops[i + 1].up_idx == (int)i && upc_applies(e, e->ops[i + 1], B, H, W)) { skipped[i] = 1; continue; }
         if (op.type == OP_CONV && op.up_idx >= 0 && skipped[op.up_idx]) { reads[i] = {e->ops[op.up_idx].src, op.skip}; continue; }
         if (!(op.first_direct)) reads[i].push_back(op.src);
@@ -811,6 +814,7 @@ ActPlan plan_activations(const ts2d_engine* e, int B, int H, int W, bool keep) {
     for (size_t i = 0; i < no; ++i) {
         if (skipped[i]) continue;
         const Op& op = e->ops[i];
+        if (fused0 && i == 0) continue;                      // statistics only: no output tensor
         if (op.dst >= 0) {                                   // the output is placed while the inputs are still allocated: never on top of them
             bool r = false;
             p.off[op.dst] = alloc(bytes_of(op.dst), r); p.used[op.dst] = 1; live[op.dst] = {p.off[op.dst], bytes_of(op.dst)};
@@ -965,6 +969,20 @@ bool up0_applies(const ts2d_engine* e, const Op& op, int Ht, int Wt) {
            // a run that composes would place the block's output on a buffer the run still reads)
 }
 
+// Does the first block run as a statistics-only pass, recomputed inside the second block (conv3x3_res32<.., FUSE>)?  Depends on
+// (options, precision, H, W) only - the activation plan asks the same question.
+bool fuse0_applies(const ts2d_engine* e, int H, int W) {
+    // (split mode only.  Measured in the 16-bit mode, B = 64 canonical: 0.30 + 0.94 ms fused against 0.44 + 0.52 ms as two kernels - the
+    //  16-bit second block is HBM-bound at a third of the split block's MFMA work, and the recompute is fp32 MFMA work either way)
+    if (!e->use_fuse0 || !e->use_res || !e->use_one || e->precision != TS2D_PRECISION_F32_SPLIT_F16X3 || e->ops.size() < 3) return false;
+    const Op& o0 = e->ops[0]; const Op& o1 = e->ops[1];
+    if (!o0.first_direct || o0.cout != 32 || e->arch.input_channels > 2) return false;
+    if (o1.type != OP_CONV || !o1.res_ok || o1.src != o0.dst || o1.skip >= 0) return false;
+    for (size_t i = 2; i < e->ops.size(); ++i) if (e->ops[i].src == o0.dst || e->ops[i].skip == o0.dst) return false;      // (a one-conv stage: the tensor is a skip)
+    if (H % 8 || W % 32) return false;
+    return (size_t)H * W * 32 * 4 < ((size_t)1 << 31) && (size_t)e->arch.input_channels * H * W * 4 < ((size_t)1 << 31);
+}
+
 bool upc_applies(const ts2d_engine* e, const Op& op, int B, int H, int W) {
     if (!op.upc_ok || !e->use_upc || !e->use_one || e->precision == TS2D_PRECISION_F32_EXACT) return false;
     if (e->precision == TS2D_PRECISION_F16 && (op.cin_skip % 32 || !e->tensors[e->ops[op.up_idx].src].normed || !e->tensors[op.skip].normed))
@@ -1019,12 +1037,21 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const bool first_full = g.lgNIMG == 0 && g.lgTH + g.lgTW == 8 && g.lgTW >= 4 && H % (1 << g.lgTH) == 0 && W % (1 << g.lgTW) == 0 &&
                                     P * 2 * kp <= 4 * kBlock && (size_t)H * W * op.cout * 4 < ((size_t)1 << 31);
             const int grid_first = first_full ? std::min(g.n_mtiles, e->num_cus * (nt == 1 ? 4 : 2)) : g.n_mtiles;
+            const bool stats_only = fuse0_applies(e, H, W);           // (implies first_full geometry, nt == 1, kp == 1)
+            if (stats_only) {
+                if (!first_full || !fused) return fail(TS2D_ERR_INVALID, "internal: fused first block on a geometry without complete tiles");
+                prof_kernel(e, "conv3x3_first_stats");
+                if (f16) hipLaunchKernelGGL((conv3x3_first<1, 1, _Float16, true, false>), dim3(grid_first), dim3(kBlock), smem, st, fa);
+                else hipLaunchKernelGGL((conv3x3_first<1, 1, float, true, false>), dim3(grid_first), dim3(kBlock), smem, st, fa);
+                e->fused_away[0] = 1;
+            }
 #define TS2D_FIRST(NT_, KP_) do { \
                 if (first_full) { if (f16) hipLaunchKernelGGL((conv3x3_first<NT_, KP_, _Float16, true>), dim3(grid_first), dim3(kBlock), smem, st, fa); \
                                   else hipLaunchKernelGGL((conv3x3_first<NT_, KP_, float, true>), dim3(grid_first), dim3(kBlock), smem, st, fa); } \
                 else { if (f16) hipLaunchKernelGGL((conv3x3_first<NT_, KP_, _Float16, false>), dim3(grid_first), dim3(kBlock), smem, st, fa); \
                        else hipLaunchKernelGGL((conv3x3_first<NT_, KP_, float, false>), dim3(grid_first), dim3(kBlock), smem, st, fa); } } while (0)
-            if (nt == 1 && kp == 1) TS2D_FIRST(1, 1);
+            if (stats_only) {}
+            else if (nt == 1 && kp == 1) TS2D_FIRST(1, 1);
             else if (nt == 1 && kp == 2) TS2D_FIRST(1, 2);
             else if (nt == 2 && kp == 1) TS2D_FIRST(2, 1);
             else if (nt == 2 && kp == 2) TS2D_FIRST(2, 2);
@@ -1211,16 +1238,18 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 for (int d = 1; d <= tpi_r; ++d) if (tpi_r % d == 0 && ra.n_tiles / d >= want) seg = d;
                 ra.seg = seg;
                 const int nbk = ra.n_tiles / seg;
-                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_res32");
-                if (f16) {
-                    static std::atomic<uint64_t> done16{0};
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_res32<_Float16, 1>), done16));
-                    hipLaunchKernelGGL((conv3x3_res32<_Float16, 1>), dim3(nbk), dim3(kBlock), 9 * 4 * 512 + 4 * kResPS + 1536, st, ra);
-                } else {
-                    static std::atomic<uint64_t> done32{0};
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_res32<float, 3>), done32));
-                    hipLaunchKernelGGL((conv3x3_res32<float, 3>), dim3(nbk), dim3(kBlock), 9 * 2 * 4 * 512 + 8 * kResPS, st, ra);
+                const bool fuse0 = oi == 1 && e->fused_away[0];       // the first block was a statistics-only pass: recompute it here
+                if (fuse0) {
+                    const Op& o0 = e->ops[0];
+                    ra.src = nullptr; ra.x0 = d_in; ra.C0 = o0.cin; ra.w0 = wts + o0.dev_wraw; ra.b0 = wts + o0.dev_b;
                 }
+                TRY(prof_begin(e, op.name, st)); prof_kernel(e, fuse0 ? "conv3x3_res32f" : "conv3x3_res32");
+#define TS2D_RES32(ST_, NP_, FUSE_, LDS_) do { static std::atomic<uint64_t> done_{0}; \
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_res32<ST_, NP_, FUSE_>), done_)); \
+                    hipLaunchKernelGGL((conv3x3_res32<ST_, NP_, FUSE_>), dim3(nbk), dim3(kBlock), LDS_, st, ra); } while (0)
+                if (f16) { if (fuse0) TS2D_RES32(_Float16, 1, true, 9 * 4 * 512 + 4 * kResPS + 1536); else TS2D_RES32(_Float16, 1, false, 9 * 4 * 512 + 4 * kResPS + 1536); }
+                else { if (fuse0) TS2D_RES32(float, 3, true, 9 * 2 * 4 * 512 + 8 * kResPS); else TS2D_RES32(float, 3, false, 9 * 2 * 4 * 512 + 8 * kResPS); }
+#undef TS2D_RES32
                 HIP_TRY(hipGetLastError());
                 TRY(prof_end(e, st));
                 TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
@@ -1814,6 +1843,10 @@ int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_
     if (t.data && !t.resident)
         return fail(TS2D_ERR_STATE, "tensor '%s' was overwritten by a later activation of the same run (buffers are shared by liveness): "
                     "call ts2d_engine_set_keep_activations(e, 1) before the forward", name);
+    for (size_t oi = 0; oi < e->ops.size() && oi < e->fused_away.size(); ++oi)
+        if (e->fused_away[oi] && e->ops[oi].dst == ti && oi == 0)
+            return fail(TS2D_ERR_INVALID, "tensor '%s' was not materialised by the last run: the first block is recomputed inside the second "
+                        "(ts2d_engine_set_option(e, \"fuse0\", 0) runs it as its own kernel)", name);
     for (size_t oi = 0; oi < e->ops.size() && oi < e->fused_away.size(); ++oi)
         if (e->fused_away[oi] && e->ops[oi].dst == ti)
             return fail(TS2D_ERR_INVALID, "tensor '%s' was not materialised by the last run: the transposed conv is composed into the next block "

@@ -20,7 +20,9 @@ struct FirstArgs {
 
 // FULL: every tile is a complete 256-pixel tile inside one image (the engine checks) - the workgroups are persistent (grid < tiles)
 // and carry only the fast epilogue; !FULL: one tile per workgroup, both epilogues (ragged / multi-image test geometries).
-template <int NT, int KP, typename ST = float, bool FULL = false>      // NT = Cout / 32 column tiles, KP = ceil(C / 2) channel pairs, ST = output storage
+// STORE = false (round 4): the statistics-only pass in front of the fused second block (conv3x3_res32<.., FUSE>, kernels_res32.h) - the same
+// values, the same per-tile shifted partials, nothing written but them: the layer's 33.5 MB of output per slice never exist.
+template <int NT, int KP, typename ST = float, bool FULL = false, bool STORE = true>      // NT = Cout / 32 column tiles, KP = ceil(C / 2) channel pairs, ST = output storage
 __global__ __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 1) void conv3x3_first(const FirstArgs a) {
     constexpr int CP = 2 * KP + 1;               // floats per patch pixel (+1 pad: conflict-free ds_read_b32)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 1) void conv3x3_
                     const int rowoff = (i & 3) + 8 * (i >> 2);
                     const unsigned soff = (unsigned)((((rowoff & (TW - 1)) + (rowoff >> a.lgTW) * a.W) * a.Cout) * (int)sizeof(ST));
                     float v = acc[mt][nt][i] + bv;
-                    buffer_store_act<ST>(v, rsd, voff, soff);
+                    if constexpr (STORE) buffer_store_act<ST>(v, rsd, voff, soff);
                     const float d = round_act<ST>(v) - kv;
                     ss += d; qq = __builtin_fmaf(d, d, qq);
                 }

@@ -35,11 +35,24 @@ struct Res32Args {
                            // (the statistics stay per TILE: a slice computes bit-identically alone or in a batch)
     float slope;
     unsigned long long* prof;   // diagnostic (TS2D_DBG=256): cycles of wave 0 in [0] patch conversion, [1] barrier, [2] MFMAs, [3] epilogue, [4] barrier + tile partial
+    // FUSE variant (round 4): `src` is never read - the producing block (the network's FIRST block: C0 <= 2 input channels -> 32, exact
+    // fp32 MFMA as conv3x3_first computes it) is recomputed per tile from the NCHW network input; sc / sh are ITS scale / shift, known
+    // from a statistics-only pass of conv3x3_first.
+    const float* x0; int C0;           // network input [B, C0, H, W] fp32
+    const float* w0; const float* b0;  // first block: weights [32][C0][3][3] (PyTorch layout), bias [32]
 };
 
 constexpr int kResPW = 34, kResP = 340, kResPS = 352 * 16;      // patch 10 x 34 pixels; plane stride (bytes)
 
-template <typename ST, int NP>
+// FUSE (round 4): the block in front (enc0.c0: 2 -> 32 channels at full resolution) is the one tensor of the net that is
+// written once (33.5 MB per slice) only to be read back by this kernel.  With FUSE the kernel reads the 2-channel network input
+// instead (12 x 36 input pixels per tile, straight from L1 / L2 into the B operand of v_mfma_f32_32x32x2_f32: 27 dword loads per lane,
+// prefetched across the tile boundary like the patch before), recomputes enc0.c0 for the 340 patch pixels as 11 M tiles of 32 pixels
+// (TRANSPOSED product: rows = channels, so that a lane holds 4 consecutive channels of one pixel = half a 16-byte LDS slot),
+// normalises with the scale / shift of a statistics-only pass, applies LeakyReLU, zeroes what lies outside the image (the padding of
+// THIS conv), splits hi / lo and writes the same k-group-major planes the MFMA phase reads.  Cost per tile and wave: 27 fp32 MFMAs of
+// 64 cycles beside the 216 (x 16 cycles) of the block itself; saved: 4.3 GB of HBM traffic per 64-slice step.
+template <typename ST, int NP, bool FUSE = false>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
     constexpr int NPP = NP == 3 ? 2 : 1;                   // fp16 parts per value (hi, lo)
     constexpr int WB = 9 * NPP * 4 * 512;                  // resident weights (bytes)
@@ -83,30 +96,90 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
     //      one wave instruction covers 16 whole pixels (every byte of their 128-byte records), 8 consecutive lanes write 8
     //      consecutive 16-byte slots of one plane (conflict-free ds_write_b128).
     const int sg = (lane >> 3) & 3, pl = (lane & 7) + 8 * (lane >> 5);
-    unsigned rel[NU];          // byte offset of the unit's 8 channels relative to the patch origin (ty0 - 1, tx0 - 1)
+    unsigned rel[FUSE ? 1 : NU];          // byte offset of the unit's 8 channels relative to the patch origin (ty0 - 1, tx0 - 1)
     unsigned emask = 0;        // per unit 4 bits: patch row 0 / row 9 / column 0 / column 33 (the padding candidates)
-#pragma unroll
-    for (int it = 0; it < NU; ++it) {
-        const int p = 64 * it + 16 * w + pl;
-        const int py = p / kResPW, px = p - py * kResPW;
-        rel[it] = (unsigned)(((py * a.W + px) * 32 + 8 * sg) * (int)sizeof(ST));
-        if (p < kResP) emask |= ((py == 0 ? 1u : 0u) | (py == 9 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == kResPW - 1 ? 8u : 0u)) << (4 * it);
-    }
-    const bool last_unit = 64 * (NU - 1) + 16 * w + pl < kResP;          // unit NU-1 exists for this thread
+    bool last_unit = false;
     const int swr = sg * kResPS + (16 * w + pl) * 16;      // LDS write address of unit 0 (hi part); unit it: + 1024 it
-
     const size_t img_bytes = (size_t)a.H * a.W * 32 * sizeof(ST);
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.src)) + (size_t)n * img_bytes,
-                                                      0, (int)img_bytes, 0x00020000);
-    u32x4 pv[NU][NL];
+    u32x4 pv[FUSE ? 1 : NU][NL];
+    // FUSE: M tile k of this wave = patch pixels p = 32 (w + 4 k) + r2, k = 0..2 (11 M tiles: wave 3 has two; pixels >= 340 are not written)
+    const int r2 = lane & 31, h2 = lane >> 5;              // lane roles in the 32x32x2 fp32 MFMA: column (pixel) / k (input channel)
+    constexpr int NK = 3;
+    unsigned xrel[FUSE ? NK : 1], pq[FUSE ? NK : 1];       // input byte offset of (py, px) of channel h2 relative to the input-patch origin; (py << 8) | px
+    float xv[FUSE ? NK : 1][FUSE ? 9 : 1];                 // the 27 prefetched input values
+    float wr0[FUSE ? 9 : 1], scq[FUSE ? 16 : 1], shq[FUSE ? 16 : 1];
+    float bq[(FUSE && sizeof(ST) != 4) ? 16 : 1];
+    const bool have3 = w != 3;                             // (wave-uniform)
+    __amdgpu_buffer_rsrc_t rs, rsx;
+    if constexpr (!FUSE) {
+#pragma unroll
+        for (int it = 0; it < NU; ++it) {
+            const int p = 64 * it + 16 * w + pl;
+            const int py = p / kResPW, px = p - py * kResPW;
+            rel[it] = (unsigned)(((py * a.W + px) * 32 + 8 * sg) * (int)sizeof(ST));
+            if (p < kResP) emask |= ((py == 0 ? 1u : 0u) | (py == 9 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == kResPW - 1 ? 8u : 0u)) << (4 * it);
+        }
+        last_unit = 64 * (NU - 1) + 16 * w + pl < kResP;          // unit NU-1 exists for this thread
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.src)) + (size_t)n * img_bytes,
+                                               0, (int)img_bytes, 0x00020000);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int p = 32 * (w + 4 * k) + r2;
+            const int py = p / kResPW, px = p - py * kResPW;
+            xrel[k] = (unsigned)(((h2 * a.H + py) * a.W + px) * 4);
+            pq[k] = (unsigned)((py << 8) | px);
+            if (p < kResP) emask |= ((py == 0 ? 1u : 0u) | (py == 9 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == kResPW - 1 ? 8u : 0u)) << (4 * k);
+        }
+        const size_t in_bytes = (size_t)a.C0 * a.H * a.W * 4;
+        rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0) + (size_t)n * a.C0 * a.H * a.W, 0, (int)in_bytes, 0x00020000);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wr0[tap] = h2 < a.C0 ? a.w0[((size_t)r2 * a.C0 + h2) * 9 + tap] : 0.f;      // A[m = channel r2][k = input channel h2]
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                     // rows of the 32x32 product held by this lane: channel (i & 3) + 8 (i >> 2) + 4 h2
+            const int c = (i & 3) + 8 * (i >> 2) + 4 * h2;
+            const float s_ = a.sc[(size_t)n * 32 + c], t_ = a.sh[(size_t)n * 32 + c], b_ = a.b0[c];
+            scq[i] = s_;
+            if constexpr (sizeof(ST) == 4) shq[i] = __builtin_fmaf(b_, s_, t_);      // (acc + b) s + t = acc s + (b s + t)
+            else { shq[i] = t_; bq[i] = b_; }                                       // 16-bit mode: the raw value is rounded to fp16 first, as if stored
+        }
+    }
     auto prefetch = [&](int ptx, int pty) {
-        // origin may lie one row / column outside the image: unsigned wrap-around is fine, the affected units are padding
-        const unsigned org = (unsigned)((((pty * 8 - 1) * a.W + (ptx * 32 - 1)) * 32) * (int)sizeof(ST));
+        if constexpr (!FUSE) {
+            // origin may lie one row / column outside the image: unsigned wrap-around is fine, the affected units are padding
+            const unsigned org = (unsigned)((((pty * 8 - 1) * a.W + (ptx * 32 - 1)) * 32) * (int)sizeof(ST));
 #pragma unroll
-        for (int it = 0; it < NU; ++it)
+            for (int it = 0; it < NU; ++it)
 #pragma unroll
-            for (int l = 0; l < NL; ++l)
-                pv[it][l] = __builtin_amdgcn_raw_buffer_load_b128(rs, org + rel[it] + 16 * l, 0, 0);
+                for (int l = 0; l < NL; ++l)
+                    pv[it][l] = __builtin_amdgcn_raw_buffer_load_b128(rs, org + rel[it] + 16 * l, 0, 0);
+        } else {
+            // input patch origin (ty0 - 2, tx0 - 2).  Interior tiles: every address lies inside the image (a lane with h2 >= C0 is beyond
+            // the buffer's range and reads 0).  Border tiles: the first conv's own zero padding, per load.
+            const int oy0 = pty * 8 - 2, ox0 = ptx * 32 - 2;
+            const bool pe = (pty == 0) | (pty == a.tiles_y - 1) | (ptx == 0) | (ptx == a.tiles_x - 1);      // wave-uniform
+            const unsigned org = (unsigned)((oy0 * a.W + ox0) * 4);
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                if (k < NK - 1 || have3) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int dy = tap / 3, dx = tap - 3 * dy;
+                        // (the buffer's range check looks at the VGPR offset alone: on a border tile the origin can be "negative", so the
+                        //  tap offset goes into the VGPR there; interior tiles keep it in the scalar offset)
+                        unsigned vo = org + xrel[k];
+                        unsigned so = (unsigned)((dy * a.W + dx) * 4);
+                        if (pe) {
+                            const int iy = oy0 + (int)(pq[k] >> 8) + dy, ix = ox0 + (int)(pq[k] & 255u) + dx;
+                            const bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W) & (h2 < a.C0);
+                            vo = ok ? vo + so : 0x80000000u;
+                            so = 0;
+                        }
+                        xv[k][tap] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, vo, so, 0));
+                    }
+                }
+            }
+        }
     };
     prefetch(txi, tyi);
 
@@ -125,12 +198,18 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.dst) + (size_t)n * img_bytes, 0, (int)img_bytes, 0x00020000);
     // scale / shift of this thread's 8 staging channels (image n)
     const float* ps = a.sc + (size_t)n * 32 + 8 * sg; const float* pt = a.sh + (size_t)n * 32 + 8 * sg;
-    const f32x4 nsa = *reinterpret_cast<const f32x4*>(ps), nsb = *reinterpret_cast<const f32x4*>(ps + 4);
-    const f32x4 nta = *reinterpret_cast<const f32x4*>(pt), ntb = *reinterpret_cast<const f32x4*>(pt + 4);
+    f32x4 nsa, nsb, nta, ntb;
+    if constexpr (!FUSE) {
+        nsa = *reinterpret_cast<const f32x4*>(ps); nsb = *reinterpret_cast<const f32x4*>(ps + 4);
+        nta = *reinterpret_cast<const f32x4*>(pt); ntb = *reinterpret_cast<const f32x4*>(pt + 4);
+    }
     const f32x4 slope4 = f32x4{a.slope, a.slope, a.slope, a.slope};
 
     TS2D_PROF_DECL(a.prof);
     for (int t = t0; t < t1; ++t) {
+        // tiles on the image border: the patch rows / columns outside the image are zero padding (AFTER norm + activation)
+        const unsigned edge = (tyi == 0 ? 1u : 0u) | (tyi == a.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) | (txi == a.tiles_x - 1 ? 8u : 0u);
+        if constexpr (!FUSE) {
         // ---- patch: InstanceNorm + LeakyReLU on the fly, split into fp16 hi / lo, written k-group major
 #pragma unroll
         for (int it = 0; it < NU; ++it) {
@@ -152,8 +231,6 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
                 }
             }
         }
-        // tiles on the image border: the patch rows / columns outside the image are zero padding (AFTER norm + activation)
-        const unsigned edge = (tyi == 0 ? 1u : 0u) | (tyi == a.tiles_y - 1 ? 2u : 0u) | (txi == 0 ? 4u : 0u) | (txi == a.tiles_x - 1 ? 8u : 0u);
         if (edge) {                                        // wave-uniform; 15 % of the tiles of a 512 x 512 image
             const unsigned hit = emask & (edge * 0x111111u);
 #pragma unroll
@@ -163,6 +240,55 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
                     *reinterpret_cast<uint4*>(d) = uint4{0u, 0u, 0u, 0u};
                     if (NPP == 2) *reinterpret_cast<uint4*>(d + 4 * kResPS) = uint4{0u, 0u, 0u, 0u};
                 }
+        }
+        } else {
+        // ---- FUSE: recompute the first block on the patch pixels of this wave's M tiles, normalise, activate, split, write the planes
+        const unsigned hit = edge ? (emask & (edge * 0x111u)) : 0u;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            if (k < NK - 1 || have3) {
+                f32x16 acc0 = kZero16;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wr0[tap], xv[k][tap], acc0, 0, 0, 0);
+                const bool zero = (hit >> (4 * k)) & 0xFu;                        // this lane's pixel lies outside the image
+                const int p = 32 * (w + 4 * k) + r2;
+                unsigned char* d = sP + p * 16 + 8 * h2;                          // plane g = quad index: + g * kResPS; lo part: + 4 * kResPS
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                if constexpr (sizeof(ST) == 4) {
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const float y = __builtin_fmaf(acc0[i], scq[i], shq[i]); v[i] = fmaxf(y, y * a.slope); }
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        uint4 hi, lo;
+                        split_hi_lo_8(f32x4{v[8 * qq], v[8 * qq + 1], v[8 * qq + 2], v[8 * qq + 3]},
+                                      f32x4{v[8 * qq + 4], v[8 * qq + 5], v[8 * qq + 6], v[8 * qq + 7]}, hi, lo);
+                        if (zero) { hi = uint4{0u, 0u, 0u, 0u}; lo = hi; }
+                        if (k < NK - 1 || p < kResP) {
+                            *reinterpret_cast<u32x2*>(d + (2 * qq) * kResPS) = u32x2{hi.x, hi.y};
+                            *reinterpret_cast<u32x2*>(d + (2 * qq + 1) * kResPS) = u32x2{hi.z, hi.w};
+                            *reinterpret_cast<u32x2*>(d + (2 * qq + 4) * kResPS) = u32x2{lo.x, lo.y};
+                            *reinterpret_cast<u32x2*>(d + (2 * qq + 5) * kResPS) = u32x2{lo.z, lo.w};
+                        }
+                    }
+                } else {
+                    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        half4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = 4 * q + e;
+                            const float raw = (float)(_Float16)(acc0[i] + bq[i]);                     // as stored by conv3x3_first in this mode
+                            const _Float16 y = (_Float16)__builtin_fmaf(raw, scq[i], shq[i]);         // norm_lrelu_8: fp32 FMA, one rounding,
+                            const _Float16 ng = y * slope_h;                                          // LeakyReLU in fp16
+                            o[e] = zero ? (_Float16)0.f : (y > ng ? y : ng);
+                        }
+                        if (k < NK - 1 || p < kResP) *reinterpret_cast<half4*>(d + q * kResPS) = o;
+                    }
+                }
+            }
+        }
         }
         TS2D_STAMP_AT(a.prof, 0)
         lds_barrier();                                     // patch (and, first tile, the weights) visible to every wave
@@ -274,8 +400,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
         }
         TS2D_STAMP_AT(a.prof, 3)
         lds_barrier();                                     // every wave is done with the patch; the scratch is complete (stores in flight)
-        if (tid < 32) {                                    // tile partial (fixed order over the 4 waves, rebased onto wave 0's pivot)
-            const int co = tid, cb = co >> 4, gg = (co >> 2) & 3, i = co & 3;
+        // tile partial (fixed order over the 4 waves, rebased onto wave 0's pivot).  FUSE: by wave 3, which has one M tile less to
+        // recompute in the next tile's first phase (the other waves would wait for wave 0 at the next barrier)
+        if (FUSE ? (tid >= 192 && tid < 224) : tid < 32) {
+            const int co = tid & 31, cb = co >> 4, gg = (co >> 2) & 3, i = co & 3;
             const float* s0 = scratch(0, gg) + cb * 12 + i;
             f32x4 acc4 = f32x4{s0[0], s0[4], s0[8], 64.f};
 #pragma unroll
