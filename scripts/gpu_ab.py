@@ -24,7 +24,11 @@ blob = weights.pack_blob(a, weights.synthetic_state_dict(a, 1))
 engines = []
 for v in args.variants:
     opts = {} if v == '-' else {kv.split('=')[0]: int(kv.split('=')[1]) for kv in v.split(',')}
+    dbg = opts.pop('dbg', None)                  # pseudo-option: TS2D_DBG (diagnostic switches inside kernels), read at engine creation
+    if dbg is not None:
+        os.environ['TS2D_DBG'] = str(dbg)
     e = Engine(a, blob, options=opts)
+    os.environ.pop('TS2D_DBG', None)
     e.set_precision(args.mode)
     engines.append(e)
 xd = torch.randn(args.batch, 2, 512, 512, device='cuda')
