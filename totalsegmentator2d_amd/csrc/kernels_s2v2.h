@@ -14,6 +14,18 @@
 //     row), so that the stride-2 pixel walk of a fragment is a walk over consecutive slots.
 //   * the weight block of a (chunk, column tile) is stored in HBM in LDS order and copied linearly.
 // Arithmetic as in kernels_f16x3.h (split: hi/lo fp16, 3 products, fresh accumulator per chunk; f16: one product).
+//
+// Round 4.  In-kernel stamps (profiles/r04_phase_stamps.txt, enc2.c0, per item of 6.9 k cycles of MFMAs): 5.2 k cycles between the
+// conversion barrier and the first MFMA - the wave sat at the ISSUE of the next item's ten patch loads.  Each of those wave
+// instructions touched 32 different 128-byte lines (32 pixels x 2 lanes x 16 bytes) and the address path retires about one line per
+// cycle: 80 instructions x ~64 cycles per item and CU, all eight waves queueing at once in front of their MFMAs.  Now (fp32 storage):
+//   * FOUR lanes per pixel: a lane loads one 16-byte quarter of the chunk's 64-byte slice, a wave instruction covers 16 pixels =
+//     16 lines (the conversion works on 4 channels per unit, the LDS writes are ds_write_b64);
+//   * the loads are SPREAD over the item's taps, one unit per tap, instead of being issued in one burst;
+//   * the per-chunk weight block travels L2 -> LDS by global_load_lds instead of through registers and ds_write_b128 (72 wave stores
+//     per item less on the LDS store path; 36 registers, which pay for the next point);
+//   * BN = 128 reads the next tap's fragments during the current tap's MFMAs, as BN = 64 did;
+//   * the zero-selects of the padding units run on border tiles only (wave-uniform branch).
 #pragma once
 #include "kernels_f16x3.h"
 #include "kernels_h32.h"
@@ -22,6 +34,21 @@ namespace ts2d {
 
 constexpr int kS2Threads = 512;
 constexpr int kS2PW = 66, kS2Slots = 17 * kS2PW, kS2Plane = kS2Slots * 16;      // patch: 17 rows x (33 even + 33 odd columns)
+
+// fp32 x 4 -> fp16 hi[4] + lo[4] (x = hi + lo to 22 bits): the 4-value form of split_hi_lo_8 (kernels_f16x3.h)
+__device__ __forceinline__ void split_hi_lo_4(const f32x4& v, uint2& hi, uint2& lo) {
+    unsigned h0, h1, l0, l1;
+    asm volatile(
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    hi = uint2{h0, h1}; lo = uint2{l0, l1};
+}
 
 // Round 3: PERSISTENT workgroups.  In-kernel stamps of round 2 (profiles/r02_phase_stamps.txt, enc1.c0): of ~27 000 cycles per
 // two-chunk workgroup 8 800 were spent waiting for the first chunk's patch - one workgroup per CU (LDS), nothing else resident to
@@ -36,16 +63,15 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     constexpr int NPP = NP == 3 ? 2 : 1;                   // fp16 parts per value
     constexpr int NTW = BN / 64;                           // 32-column MFMA tiles per wave (a wave owns BN / 2 columns)
     constexpr int WTAP = NPP * 2 * BN * 16, WB = 9 * WTAP; // weight bytes per tap / per chunk
-    constexpr int MAXU = 5;                                // staging units per thread: 5 x 256 slots >= 1122
-    constexpr int NL = sizeof(ST) == 4 ? 2 : 1;            // 16-byte loads per unit (8 channels)
-    constexpr int WIT = (WB / 16 + kS2Threads - 1) / kS2Threads;
-    constexpr bool PFS = BN == 64;                         // scale / shift prefetched with the patch (BN = 128: no registers left - loaded at the item's start)
-    constexpr int DEPTH = BN == 64 ? 2 : 1;                // items kept in flight in registers.  In-kernel stamps (enc1.c0, depth 1): the "MFMA" phases take
-                                                           // 6-8 k cycles for 1.7 k of MFMAs - the wave sits at the ISSUE of the next item's loads behind the previous tile's
-                                                           // stores: a CU moves ~10 B per cycle to / from HBM (guide), 175 KB per tile = 17 k of the tile's 26 k cycles, and
-                                                           // with one item in flight that pipe idles during every conversion / epilogue.  Two items keep it fed.
+    constexpr bool F32 = sizeof(ST) == 4;
+    // staging unit = 16 bytes of a pixel's 16-channel slice.  fp32 storage: a quarter (4 channels), four lanes per pixel, 9 units per
+    // thread (9 x 128 slots >= 1122); fp16 storage: a half (8 channels), two lanes per pixel, 5 units per thread (5 x 256 slots)
+    constexpr int MAXU = F32 ? 9 : 5;
+    constexpr int USTEP = F32 ? 128 : 256;                 // slots covered by one unit index of the whole workgroup
+    constexpr int DEPTH = BN == 64 ? 2 : 1;                // items kept in flight in registers (BN = 64: enc1.c0 runs at the HBM rate; two items keep that pipe fed)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void* lds_ptr;
 
     // ---- this workgroup's tiles: virtual block v = blockIdx.x + k * gridDim.x -> (xcd, column tile) fixed, pixel tile mtile0 + k * mstep
     const int xcd = blockIdx.x & 7, q80 = blockIdx.x >> 3;
@@ -63,27 +89,34 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     unsigned char* sA = smem8;                             // [part][h][slot] x 16 B
     unsigned char* sB = smem8 + NPP * 2 * kS2Plane;        // [chunk (RESW)][tap][part][h][column BN] x 16 B
 
-    // ---- staging plan (tile-independent).  A wave instruction covers 32 slots x 2 channel octets: slot = 32 (8 it + w) + (lane & 7) +
-    //      8 (lane >> 4), octet = (lane >> 3) & 1 - 8 consecutive lanes write 8 consecutive slots of one plane.  Slot q = patch row
-    //      q / 66, then the 33 even columns, then the 33 odd ones (the 66th slot of a row is unused).
-    const int oct = (lane >> 3) & 1;
-    unsigned rel[MAXU];                                    // byte offset of the unit's 8 channels from the patch origin, 0x80000000 = no unit
+    // ---- staging plan (tile-independent).  Slot q = patch row q / 66, then the 33 even columns, then the 33 odd ones (the 66th slot of
+    //      a row is unused).  fp32: unit it of thread tid = slot (tid >> 2) + 128 it, quarter sub = tid & 3 (channels 4 sub .. 4 sub + 3 of the
+    //      chunk: plane h = sub >> 1, bytes 8 (sub & 1) .. of the slot); fp16: slot 32 (8 it + w) + (lane & 7) + 8 (lane >> 4), octet
+    //      sub = (lane >> 3) & 1 (plane h = sub).
+    const int sub = F32 ? (tid & 3) : ((lane >> 3) & 1);
+    const int slot0 = F32 ? (tid >> 2) : (32 * w + (lane & 7) + 8 * (lane >> 4));
+    unsigned rel[MAXU];                                    // byte offset of the unit from the patch origin, 0x80000000 = no unit
     unsigned emask = 0;                                    // per unit: bit 0 = patch row 0, bit 1 = patch column 0 (the padding candidates)
-    const int lw0 = oct * kS2Plane + (32 * w + (lane & 7) + 8 * (lane >> 4)) * 16;      // LDS write address of unit 0; unit it: + 4096 it
+    const int lw0 = F32 ? (sub >> 1) * kS2Plane + slot0 * 16 + (sub & 1) * 8 : sub * kS2Plane + slot0 * 16;      // LDS write address of unit 0; unit it: + 16 USTEP it
 #pragma unroll
     for (int it = 0; it < MAXU; ++it) {
-        const int q = 32 * (8 * it + w) + (lane & 7) + 8 * (lane >> 4);
+        const int q = slot0 + USTEP * it;
         const int py = q / kS2PW, rem = q - py * kS2PW;
         const int half = rem >= 33 ? 1 : 0, px = 2 * (rem - 33 * half) + half;
         const bool exists = q < kS2Slots && px <= 64;
-        rel[it] = exists ? (unsigned)(((py * a.Win + px) * a.C0 + 8 * oct) * (int)sizeof(ST)) : 0x80000000u;
+        rel[it] = exists ? (unsigned)(((py * a.Win + px) * a.C0) * (int)sizeof(ST) + 16 * sub) : 0x80000000u;
         if (exists) emask |= ((py == 0 ? 1u : 0u) | (px == 0 ? 2u : 0u)) << (2 * it);
         if (q < kS2Slots && !exists) {                     // the unused 66th slot of a row: zero once (never staged, read by no fragment)
-            *reinterpret_cast<uint4*>(sA + lw0 + it * 4096) = uint4{0u, 0u, 0u, 0u};
-            if (NPP == 2) *reinterpret_cast<uint4*>(sA + lw0 + it * 4096 + 2 * kS2Plane) = uint4{0u, 0u, 0u, 0u};
+            if constexpr (F32) {
+                *reinterpret_cast<uint2*>(sA + lw0 + it * USTEP * 16) = uint2{0u, 0u};
+                if (NPP == 2) *reinterpret_cast<uint2*>(sA + lw0 + it * USTEP * 16 + 2 * kS2Plane) = uint2{0u, 0u};
+            } else {
+                *reinterpret_cast<uint4*>(sA + lw0 + it * USTEP * 16) = uint4{0u, 0u, 0u, 0u};
+            }
         }
     }
     if constexpr (RESW) {                                  // resident weights: chunks x 9 taps of this column tile, one linear copy each
+        constexpr int WIT = (WB / 16 + kS2Threads - 1) / kS2Threads;
         for (int c = 0; c < nchunks; ++c) {
             const uint4* wsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(a.wph) + ((size_t)c * a.n_ctiles + ctile) * (9 * 2 * 2 * BN * 16));
 #pragma unroll
@@ -107,35 +140,52 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         tyi = tin >> a.lg_tx; txi = tin - tyi * a.tiles_x;
     };
     const size_t img_px = (size_t)a.Hin * a.Win;
-    struct Stage { u32x4 pv[MAXU][NL]; f32x4 nsa, nsb, nta, ntb; };      // raw patch + scale / shift of one item in flight
+    // raw patch + scale / shift of one item in flight (fp32: 4 channels per thread -> nsa / nta only; fp16: 8 channels)
+    struct Stage { u32x4 pv[MAXU]; f32x4 nsa, nsb, nta, ntb; };
     Stage sg0, sg1;
     const bool normed = a.sc0 != nullptr;
-    auto load_norm = [&](Stage& S, int nimg, int c) {      // scale / shift of this thread's 8 channels (not normalised: loaded, not used)
-        const float* ps = (normed ? a.sc0 : a.bias) + (normed ? (size_t)nimg * a.C0 + c * 16 + 8 * oct : 0);
-        const float* pt = (normed ? a.sh0 : a.bias) + (normed ? (size_t)nimg * a.C0 + c * 16 + 8 * oct : 0);
-        S.nsa = *reinterpret_cast<const f32x4*>(ps); S.nsb = *reinterpret_cast<const f32x4*>(ps + 4);
-        S.nta = *reinterpret_cast<const f32x4*>(pt); S.ntb = *reinterpret_cast<const f32x4*>(pt + 4);
+    auto load_norm = [&](Stage& S, int nimg, int c) {      // scale / shift of this thread's channels (not normalised: loaded, not used)
+        const int co = F32 ? 4 * sub : 8 * sub;
+        const float* ps = (normed ? a.sc0 : a.bias) + (normed ? (size_t)nimg * a.C0 + c * 16 + co : 0);
+        const float* pt = (normed ? a.sh0 : a.bias) + (normed ? (size_t)nimg * a.C0 + c * 16 + co : 0);
+        S.nsa = *reinterpret_cast<const f32x4*>(ps); S.nta = *reinterpret_cast<const f32x4*>(pt);
+        if constexpr (!F32) { S.nsb = *reinterpret_cast<const f32x4*>(ps + 4); S.ntb = *reinterpret_cast<const f32x4*>(pt + 4); }
     };
-    auto prefetch = [&](Stage& S, const Item& t) {         // 5 (x NL) buffer loads (+ 4 global loads), branch-free
-        int nimg, tyi, txi, tin;
+    // a request = its scalar part (descriptor, origin, chunk offset) + one load per unit; the units of the NEXT request are issued one
+    // per tap inside the MFMA phase (below), the very first ones here in a burst
+    struct Req { __amdgpu_buffer_rsrc_t rs; unsigned org; int soff; };
+    auto request = [&](const Item& t, int& nimg) {
+        int tyi, txi, tin;
         tile_origin(t.k, nimg, tyi, txi, tin);
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<ST*>(reinterpret_cast<const ST*>(a.src0)) + (size_t)nimg * img_px * a.C0, 0,
-                                                          (int)(img_px * a.C0 * sizeof(ST)), 0x00020000);
+        Req q;
+        q.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<ST*>(reinterpret_cast<const ST*>(a.src0)) + (size_t)nimg * img_px * a.C0, 0,
+                                                 (int)(img_px * a.C0 * sizeof(ST)), 0x00020000);
         // patch origin (2 ty0 - 1, 2 tx0 - 1) may lie one row / column outside the image: unsigned wrap-around is fine, the affected
         // units are padding (zeroed at conversion)
-        const unsigned org = (unsigned)((((16 * tyi - 1) * a.Win + 64 * txi - 1) * a.C0) * (int)sizeof(ST));
-#pragma unroll
-        for (int it = 0; it < MAXU; ++it) {
-            const unsigned vo = rel[it] == 0x80000000u ? 0x80000000u : org + rel[it];
-#pragma unroll
-            for (int l = 0; l < NL; ++l) S.pv[it][l] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16 * l, t.c * 16 * (int)sizeof(ST), 0);
-        }
-        if constexpr (PFS) load_norm(S, nimg, t.c);
+        q.org = (unsigned)((((16 * tyi - 1) * a.Win + 64 * txi - 1) * a.C0) * (int)sizeof(ST));
+        q.soff = t.c * 16 * (int)sizeof(ST);
+        return q;
+    };
+    auto load_unit = [&](Stage& S, const Req& q, int it) {
+        const unsigned vo = rel[it] == 0x80000000u ? 0x80000000u : q.org + rel[it];
+        S.pv[it] = __builtin_amdgcn_raw_buffer_load_b128(q.rs, vo, q.soff, 0);
     };
 
     Item cur{0, 0}, pf{0, 0};                              // item being computed; last item requested
-    prefetch(sg0, cur);
-    if constexpr (DEPTH == 2) { advance(pf); prefetch(sg1, pf); }
+    {
+        int nimg;
+        const Req q = request(cur, nimg);
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) load_unit(sg0, q, it);
+        load_norm(sg0, nimg, cur.c);
+        if constexpr (DEPTH == 2) {
+            advance(pf);
+            const Req q1 = request(pf, nimg);
+#pragma unroll
+            for (int it = 0; it < MAXU; ++it) load_unit(sg1, q1, it);
+            load_norm(sg1, nimg, pf.c);
+        }
+    }
 
     // ---- lane constants of the MFMA phase: output pixel (2 wm + mt, r) reads patch row 2 (2 wm + mt) + dy, slot (dx & 1) 33 + r + (dx >> 1)
     const int abase = h * kS2Plane + ((4 * wm) * kS2PW + r) * 16;                  // + mt * 2 * 66 * 16 + part * 2 * Plane + tap offset
@@ -159,70 +209,71 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         int nimg0, tyi, txi, tin;
         tile_origin(cur.k, nimg0, tyi, txi, tin);
         const int ty0 = tyi * 8, tx0 = txi * 32;
+        TS2D_STAMP_AT(a.prof, 3)
         lds_barrier();                                     // the previous item's MFMA reads of LDS (and its statistics exchange) are done
         TS2D_STAMP_AT(a.prof, 1)                           // (LDS-only barriers: a __syncthreads() here would wait for the previous tile's output stores)
-        if constexpr (!PFS) load_norm(S, nimg0, cur.c);
         const f32x4 nsa = S.nsa, nsb = S.nsb, nta = S.nta, ntb = S.ntb;
-        // ---- weights of this chunk (not resident): one linear block; loads issued first, written to LDS behind the patch conversion
-        uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8;          // (named registers: an indexed array ends up in scratch)
+        // ---- weights of this chunk (not resident): one linear block of 1-KiB pieces, L2 -> LDS by DMA.  hipcc answers the use of ANY
+        //      register with a load pending by vmcnt(0) while a DMA is in flight: every loaded register of this item (raw patch, scale /
+        //      shift) is therefore touched - waited for - BEFORE the DMA is issued; the DMA then lands behind the conversion.
         if constexpr (!RESW) {
-            const uint4* wsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(a.wph) + ((size_t)cur.c * a.n_ctiles + ctile) * (9 * 2 * 2 * BN * 16));
-            // (f16 mode: the hi parts only - the first 2 BN slots of every 4 BN)
-#define TS2D_WLOAD(K, R) { const int sl = tid + K * kS2Threads; if (K < WIT && (WB / 16 % kS2Threads == 0 || sl < WB / 16)) \
-                R = wsrc[NPP == 2 ? sl : (sl / (2 * BN)) * (4 * BN) + sl % (2 * BN)]; }
-            TS2D_WLOAD(0, w0) TS2D_WLOAD(1, w1) TS2D_WLOAD(2, w2) TS2D_WLOAD(3, w3) TS2D_WLOAD(4, w4)
-            TS2D_WLOAD(5, w5) TS2D_WLOAD(6, w6) TS2D_WLOAD(7, w7) TS2D_WLOAD(8, w8)
-#undef TS2D_WLOAD
+#pragma unroll
+            for (int it = 0; it < MAXU; ++it) asm volatile("" :: "v"(S.pv[it]));
+            asm volatile("" :: "v"(nsa), "v"(nta));
+            if constexpr (!F32) asm volatile("" :: "v"(nsb), "v"(ntb));
+            TS2D_STAMP_AT(a.prof, 2)
+            const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wph) + ((size_t)cur.c * a.n_ctiles + ctile) * (9 * 2 * 2 * BN * 16) + lane * 16;
+            constexpr int NPIECE = WB / 1024, RUN = 2 * BN * 16 / 1024;      // f16 mode: the hi parts only - runs of RUN pieces out of every 2 RUN
+#pragma unroll
+            for (int j = 0; j < (NPIECE + 7) / 8; ++j) {
+                const int pc = w + 8 * j;
+                if (NPIECE % 8 == 0 || pc < NPIECE)
+                    __builtin_amdgcn_global_load_lds(wsrc + (NPP == 2 ? pc : (pc / RUN) * 2 * RUN + pc % RUN) * 1024, (lds_ptr)(sB + pc * 1024), 16, 0, 0);
+            }
         }
         // ---- patch: InstanceNorm + LeakyReLU on the fly, split into fp16 hi / lo; padding units store zeros
-        const unsigned pad = (tyi == 0 ? 0x155u : 0u) | (txi == 0 ? 0x2AAu : 0u);      // (uniform) which emask bits mean "outside the image" here
+        constexpr unsigned kRow0 = F32 ? 0x15555u : 0x155u, kCol0 = F32 ? 0x2AAAAu : 0x2AAu;
+        const unsigned pad = (tyi == 0 ? kRow0 : 0u) | (txi == 0 ? kCol0 : 0u);      // (uniform) which emask bits mean "outside the image" here
+        const bool border = pad != 0u;                     // (uniform) interior tiles skip the zero-selects
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
             if (rel[it] != 0x80000000u) {
-                unsigned char* d = sA + lw0 + it * 4096;
+                unsigned char* d = sA + lw0 + it * USTEP * 16;
                 const bool real = ((emask & pad) >> (2 * it) & 3u) == 0u;
-                if constexpr (sizeof(ST) == 4) {
-                    f32x4 va = __builtin_bit_cast(f32x4, S.pv[it][0]), vb = __builtin_bit_cast(f32x4, S.pv[it][NL - 1]);
+                if constexpr (F32) {
+                    f32x4 va = __builtin_bit_cast(f32x4, S.pv[it]);
                     if (normed) {
-                        va = va * nsa + nta; vb = vb * nsb + ntb;
-                        const f32x4 na = va * slope4, nb2 = vb * slope4;
+                        va = va * nsa + nta;
+                        const f32x4 na = va * slope4;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { va[e] = fmaxf(va[e], na[e]); vb[e] = fmaxf(vb[e], nb2[e]); }      // LeakyReLU (0 < slope < 1)
+                        for (int e = 0; e < 4; ++e) va[e] = fmaxf(va[e], na[e]);      // LeakyReLU (0 < slope < 1)
                     }
-                    uint4 hi, lo;
-                    split_hi_lo_8(va, vb, hi, lo);
-                    hi.x = real ? hi.x : 0u; hi.y = real ? hi.y : 0u; hi.z = real ? hi.z : 0u; hi.w = real ? hi.w : 0u;
-                    *reinterpret_cast<uint4*>(d) = hi;
-                    if (NPP == 2) {
-                        lo.x = real ? lo.x : 0u; lo.y = real ? lo.y : 0u; lo.z = real ? lo.z : 0u; lo.w = real ? lo.w : 0u;
-                        *reinterpret_cast<uint4*>(d + 2 * kS2Plane) = lo;
-                    }
+                    uint2 hi, lo;
+                    split_hi_lo_4(va, hi, lo);
+                    if (border) { hi.x = real ? hi.x : 0u; hi.y = real ? hi.y : 0u; lo.x = real ? lo.x : 0u; lo.y = real ? lo.y : 0u; }
+                    *reinterpret_cast<uint2*>(d) = hi;
+                    if (NPP == 2) *reinterpret_cast<uint2*>(d + 2 * kS2Plane) = lo;
                 } else {
-                    uint4 x = uint4{S.pv[it][0][0], S.pv[it][0][1], S.pv[it][0][2], S.pv[it][0][3]};
+                    uint4 x = uint4{S.pv[it][0], S.pv[it][1], S.pv[it][2], S.pv[it][3]};
                     if (normed) x = norm_lrelu_8(x, nsa, nsb, nta, ntb, slope2);
-                    x.x = real ? x.x : 0u; x.y = real ? x.y : 0u; x.z = real ? x.z : 0u; x.w = real ? x.w : 0u;
+                    if (border) { x.x = real ? x.x : 0u; x.y = real ? x.y : 0u; x.z = real ? x.z : 0u; x.w = real ? x.w : 0u; }
                     *reinterpret_cast<uint4*>(d) = x;
                 }
             }
         }
-        if constexpr (!RESW) {
-#define TS2D_WSTORE(K, R) { const int sl = tid + K * kS2Threads; if (K < WIT && (WB / 16 % kS2Threads == 0 || sl < WB / 16)) \
-                *reinterpret_cast<uint4*>(sB + sl * 16) = R; }
-            TS2D_WSTORE(0, w0) TS2D_WSTORE(1, w1) TS2D_WSTORE(2, w2) TS2D_WSTORE(3, w3) TS2D_WSTORE(4, w4)
-            TS2D_WSTORE(5, w5) TS2D_WSTORE(6, w6) TS2D_WSTORE(7, w7) TS2D_WSTORE(8, w8)
-#undef TS2D_WSTORE
-        }
+        TS2D_STAMP_AT(a.prof, 6)
+        if constexpr (!RESW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight DMA has landed (issued before the conversion)
         lds_barrier();
         TS2D_STAMP_AT(a.prof, 0)
         advance(pf);
-        prefetch(S, pf);                                   // the item DEPTH ahead (possibly of another tile) into the registers just converted
-
+        int nimg_pf;
+        const Req rq = request(pf, nimg_pf);               // the item DEPTH ahead (possibly of another tile) into the registers just converted:
+                                                           // its units are issued one per tap below
         f32x16 acc_c[2][NTW];                              // fresh accumulator per chunk (accuracy)
         const unsigned char* pw = smem8 + bbase + (RESW ? cur.c * WB : 0);
         __builtin_amdgcn_s_setprio(1);
         // fragments of tap t+1 are read while the MFMAs of tap t run (two register sets, one scheduling region per tap: the plain
-        // loop waited for every tap's six reads before its MFMAs - in-kernel stamps: the 54-MFMA phase took 6-8 k cycles, twice the
-        // matrix-pipe time of the two waves of a SIMD); BN = 128 keeps the plain loop (registers)
+        // loop waited for every tap's reads before its MFMAs)
         auto load_frags = [&](half8 (&fa)[2][NPP], half8 (&fb)[NTW][NPP], int tap) {
             const int dy = tap / 3, dx = tap - 3 * dy;
             const int toff = (dy * kS2PW + (dx & 1) * 33 + (dx >> 1)) * 16;
@@ -256,24 +307,21 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
                     for (int nt = 0; nt < NTW; ++nt) acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], first ? kZero16 : acc_c[mt][nt], 0, 0, 0);
             }
         };
-        if constexpr (BN == 64) {
+        {
             half8 fa0[2][NPP], fb0[NTW][NPP], fa1[2][NPP], fb1[NTW][NPP];
             load_frags(fa0, fb0, 0);
+            // one patch load of the next request per tap, behind the tap's MFMAs (units MAXU .. 8 do not exist in the 16-bit mode)
 #define TS2D_TAP2(T) { if constexpr ((T) + 1 < 9) { if constexpr ((T) & 1) load_frags(fa0, fb0, (T) + 1); else load_frags(fa1, fb1, (T) + 1); } \
                 if constexpr ((T) & 1) mma(fa1, fb1, false); else mma(fa0, fb0, (T) == 0); \
+                if constexpr ((T) < MAXU) load_unit(S, rq, (T)); \
                 __builtin_amdgcn_sched_barrier(0); }
             TS2D_TAP2(0) TS2D_TAP2(1) TS2D_TAP2(2) TS2D_TAP2(3) TS2D_TAP2(4) TS2D_TAP2(5) TS2D_TAP2(6) TS2D_TAP2(7) TS2D_TAP2(8)
 #undef TS2D_TAP2
-        } else {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                half8 fa[2][NPP], fb[NTW][NPP];
-                load_frags(fa, fb, tap);
-                mma(fa, fb, tap == 0);
-            }
         }
+        load_norm(S, nimg_pf, pf.c);
         __builtin_amdgcn_s_setprio(0);
         if (younger) __builtin_amdgcn_s_setprio(1);
+        TS2D_STAMP_AT(a.prof, 5)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -285,7 +333,6 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
             const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
             const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * sizeof(ST)), 0x00020000);
             float st_s[NTW], st_q[NTW], st_k[NTW];
-            TS2D_STAMP_AT(a.prof, 3)
             float bvs[NTW];       // every bias value before the first store: a load issued between stores waits (in-order vmcnt) for the stores ahead of it
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) bvs[nt] = a.bias[n0col + wn * (BN / 2) + nt * 32 + r];
@@ -322,7 +369,6 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
             }
             lds_barrier();
             if (tid < BN) stat_tile_store(red, 4, BN, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 4);
-            TS2D_STAMP_AT(a.prof, 5)
         }
         advance(cur);
     };
