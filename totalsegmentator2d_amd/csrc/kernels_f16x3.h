@@ -70,6 +70,21 @@ __device__ __forceinline__ void split_hi_lo_8(const f32x4& va, const f32x4& vb, 
     hi = uint4{h0, h1, h2, h3}; lo = uint4{l0, l1, l2, l3};
 }
 
+// fp32 x 4 -> fp16 hi[4] + lo[4] (x = hi + lo to 22 bits): the 4-value form of split_hi_lo_8 above
+__device__ __forceinline__ void split_hi_lo_4(const f32x4& v, uint2& hi, uint2& lo) {
+    unsigned h0, h1, l0, l1;
+    asm volatile(
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    hi = uint2{h0, h1}; lo = uint2{l0, l1};
+}
+
 // Shared epilogue: undo the weight pre-scale, add bias, store the raw NHWC output, per-tile InstanceNorm partials.
 // C/D map of the 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).
 

@@ -19,6 +19,16 @@
 // in registers per tile.  LDS: 152064 bytes + 8192 for the statistics exchange (the patch buffers stay busy).
 // Measured (gpurun r2 qp1/qp2): 64 -> 64 at level 1 0.93 (conv3x3_f16x3_p) -> 0.84-0.89 ms, 128 -> 128 0.83 -> 0.78, 256 / 512 channels
 // unchanged (0.76 / 0.74): the gain is the per-tile fill and drain, which weighs less the more chunks a tile has.
+//
+// Round 4: the raw patch loads.  In-kernel stamps (profiles/r04_phase_stamps.txt): wave 0 spent 2.3 k of an item's ~9.5 k cycles at the
+// ISSUE of the six patch loads of tap 2.  Each of those wave instructions touched 32 different 128-byte lines (32 pixels x 2 lanes x
+// 16 bytes); the address path retires about a line per cycle, and all eight waves queued their loads in one burst.  Now a staging
+// unit is ONE 16-byte quarter of a pixel's 64-byte chunk slice - four lanes per pixel, a wave instruction covers 16 pixels = 16
+// lines - five units per thread, each converted at its own tap (taps 0-4) and re-requested for the item after next right behind
+// its conversion; the weight DMA moves to tap 5 (every use of a loaded register still precedes it).  Worth 2-5 % at levels 1-2
+// (64 / 128 channels), nothing at 256 / 512: wave 0's stall at the loads was covered by its SIMD partner.  Measured NOT to help on top
+// (profiles/r04_experiments.txt): a third fewer scalar / address instructions per item (request kept across items, padding selects
+// on border tiles only) - the loop is not bound by its non-MFMA instruction count either.
 #pragma once
 #include "kernels_f16x3_one.h"
 
@@ -30,7 +40,7 @@ constexpr int kQWts = 9 * 4 * 64 * 16, kQLds = 2 * kQPatch + 2 * kQWts;      // 
 constexpr int kQpRed = kQLds, kQpLds = kQLds + 8192;          // + the statistics exchange [8 waves][64 columns] x (S, Q, K, n)
 
 __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs a) {
-    constexpr int BN = 64, NT = 2, MAXU = 3, WTAP = 4 * BN * 16;
+    constexpr int BN = 64, NT = 2, MAXU = 5, WTAP = 4 * BN * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -38,7 +48,7 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
     const int r = lane & 31, h = lane >> 5;
-    const int octi = (lane >> 3) & 1, oct = octi * 8;
+    const int sub = tid & 3;                                 // this thread's quarter of a chunk slice: channels 4 sub .. 4 sub + 3
 
     // ---- this workgroup's tiles: virtual block v = blockIdx.x + k * gridDim.x -> (xcd, column tile) fixed, pixel tile mtile0 + k * mstep
     const int xcd = blockIdx.x & 7, q80 = blockIdx.x >> 3;
@@ -53,20 +63,20 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
     const float* const sc1p = a.src1 ? a.sc1 : a.sc0;
     const float* const sh1p = a.src1 ? a.sh1 : a.sh0;
 
-    // ---- staging units: patch pixel pp = 32 (8 it + w) + (lane & 7) + 8 (lane >> 4) -> (py, px), tile-independent
-    //      (register budget: the kernel sits at the 256-register limit of two waves per SIMD - the three (py, px) pairs share ONE
-    //       register: px in 6 bits, py in 3 / 4 / 5 bits at bits 0 / 9 / 19, py >= 18 = the unit does not exist; the LDS write address of
-    //       unit it is lw0 + 4096 it.  Round 3: with the pivot of the shifted statistics two registers spilled INTO the loop.)
-    unsigned upk = 0;
+    // ---- staging units: unit it of thread tid = patch slot (tid >> 2) + 128 it -> (py, px), quarter sub; tile-independent.  (py, px) of the
+    //      five units are packed into two registers: 5 + 6 bits per unit (py = 31: the unit does not exist - slots 612 .. 639 of unit 4).
+    //      LDS write address of unit it: lw0 + 2048 it (plane h = sub >> 1, bytes 8 (sub & 1) .. of the slot); lo part: + 2 planes.
+    unsigned upk0 = 0, upk1 = 0;
 #pragma unroll
     for (int it = 0; it < MAXU; ++it) {
-        const int pp = 32 * (8 * it + w) + (lane & 7) + 8 * (lane >> 4);
-        const int py = pp / kPPW, px = pp - py * kPPW;
-        upk |= (unsigned)((py << 6) | px) << (it == 0 ? 0 : (it == 1 ? 9 : 19));
+        const int pp = (tid >> 2) + 128 * it;
+        const int py = pp < kQSlots ? pp / kPPW : 31, px = pp < kQSlots ? pp - py * kPPW : 0;
+        const unsigned f = (unsigned)((py << 6) | px);
+        if (it < 3) upk0 |= f << (11 * it); else upk1 |= f << (11 * (it - 3));
     }
-    auto unit_py = [&](int it) { return (int)((upk >> (it == 0 ? 6 : (it == 1 ? 15 : 25))) & (it == 0 ? 7u : (it == 1 ? 15u : 31u))); };
-    auto unit_px = [&](int it) { return (int)((upk >> (it == 0 ? 0 : (it == 1 ? 9 : 19))) & 63u); };
-    const int lw0 = octi * kQPlane + (32 * w + (lane & 7) + 8 * (lane >> 4)) * 16;
+    auto unit_py = [&](int it) { return (int)(((it < 3 ? upk0 >> (11 * it) : upk1 >> (11 * (it - 3))) >> 6) & 31u); };
+    auto unit_px = [&](int it) { return (int)((it < 3 ? upk0 >> (11 * it) : upk1 >> (11 * (it - 3))) & 63u); };
+    const int lw0 = (sub >> 1) * kQPlane + (tid >> 2) * 16 + (sub & 1) * 8;
     struct Item { int k, c; };                               // tile number within the workgroup, chunk
     auto advance = [&](Item& t) {                            // next item of the stream; the last item repeats (loaded / staged, never used)
         int c = t.c + 1, k = t.k;
@@ -80,51 +90,49 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
         ty0 = tyi << 4; tx0 = txi << 5;
     };
 
-    u32x4 pv[MAXU][2];
-    f32x4 nsa, nsb, nta, ntb;
-    unsigned real_pf = 0;                                    // bit it: unit it of the prefetched item lies inside the image (read by convert, which
-                                                             // runs before the next prefetch overwrites it)
-    auto prefetch = [&](const Item& t) {                     // 6 buffer loads + 4 global loads, branch-free
-        int nimg, ty0, tx0, tin;
-        tile_origin(t.k, nimg, ty0, tx0, tin);
+    u32x4 pv[MAXU];
+    f32x4 nsa, nta;
+    unsigned real_pf = 0;                                    // bit it: unit it of the item in the registers lies inside the image (set by its load,
+                                                             // read by its conversion one item later)
+    // a request = its wave-uniform part (source, descriptor, tile origin, chunk offset), computed once per item, + one load per unit
+    struct Req { __amdgpu_buffer_rsrc_t rs; int ty0, tx0, C, cb; const float* ps; const float* pt; };
+    auto request = [&](const Item& t) {
+        int nimg, tin;
+        Req q;
+        tile_origin(t.k, nimg, q.ty0, q.tx0, tin);
         const int cb0 = t.c * 16;
         const bool first = cb0 < a.C0;
-        const int cb = first ? cb0 : cb0 - a.C0, C = first ? a.C0 : a.C1;
-        const float* base = (first ? a.src0 : src1p) + (size_t)nimg * img_px * C;
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(img_px * C * 4), 0x00020000);
-        unsigned m = 0;
-#pragma unroll
-        for (int it = 0; it < MAXU; ++it) {
-            const int py = unit_py(it), px = unit_px(it);
-            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-            const bool in = (py < kQRows) & ((unsigned)iy < (unsigned)a.Hin) & ((unsigned)ix < (unsigned)a.Win);      // (bitwise: no short-circuit branches)
-            const unsigned vo = in ? (unsigned)(((iy * a.Win + ix) * C + oct) * 4) : 0x80000000u;
-            pv[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, cb * 4, 0);
-            pv[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16, cb * 4, 0);
-            m |= in ? (1u << it) : 0u;
-        }
-        real_pf = m;
-        const float* ps = (first ? a.sc0 : sc1p) + (size_t)nimg * C + cb + oct;
-        const float* pt = (first ? a.sh0 : sh1p) + (size_t)nimg * C + cb + oct;
-        nsa = *reinterpret_cast<const f32x4*>(ps); nsb = *reinterpret_cast<const f32x4*>(ps + 4);
-        nta = *reinterpret_cast<const f32x4*>(pt); ntb = *reinterpret_cast<const f32x4*>(pt + 4);
+        q.cb = first ? cb0 : cb0 - a.C0; q.C = first ? a.C0 : a.C1;
+        const float* base = (first ? a.src0 : src1p) + (size_t)nimg * img_px * q.C;
+        q.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(img_px * q.C * 4), 0x00020000);
+        q.ps = (first ? a.sc0 : sc1p) + (size_t)nimg * q.C + q.cb + 4 * sub;
+        q.pt = (first ? a.sh0 : sh1p) + (size_t)nimg * q.C + q.cb + 4 * sub;
+        return q;
+    };
+    auto load_unit = [&](const Req& q, int it) {             // one buffer load, branch-free
+        const int py = unit_py(it), px = unit_px(it);
+        const int iy = q.ty0 - 1 + py, ix = q.tx0 - 1 + px;
+        const bool in = (py < kQRows) & ((unsigned)iy < (unsigned)a.Hin) & ((unsigned)ix < (unsigned)a.Win);      // (bitwise: no short-circuit branches)
+        const unsigned vo = in ? (unsigned)(((iy * a.Win + ix) * q.C) * 4 + 16 * sub) : 0x80000000u;
+        pv[it] = __builtin_amdgcn_raw_buffer_load_b128(q.rs, vo, q.cb * 4, 0);
+        real_pf = (real_pf & ~(1u << it)) | (in ? (1u << it) : 0u);
+    };
+    auto load_norm = [&](const Req& q) {
+        nsa = *reinterpret_cast<const f32x4*>(q.ps); nta = *reinterpret_cast<const f32x4*>(q.pt);
     };
     auto convert = [&](int it, unsigned char* pb) {          // branch-free arithmetic (a padding pixel stores zeros)
-        f32x4 va = __builtin_bit_cast(f32x4, pv[it][0]), vb = __builtin_bit_cast(f32x4, pv[it][1]);
-        va = va * nsa + nta; vb = vb * nsb + ntb;
+        f32x4 va = __builtin_bit_cast(f32x4, pv[it]);
+        va = va * nsa + nta;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            va[e] = fmaxf(va[e], va[e] * a.slope);
-            vb[e] = fmaxf(vb[e], vb[e] * a.slope);
-        }
-        uint4 hi, lo;
-        split_hi_lo_8(va, vb, hi, lo);
+        for (int e = 0; e < 4; ++e) va[e] = fmaxf(va[e], va[e] * a.slope);
+        uint2 hi, lo;
+        split_hi_lo_4(va, hi, lo);
         const bool real = (real_pf >> it) & 1u;
-        hi.x = real ? hi.x : 0u; hi.y = real ? hi.y : 0u; hi.z = real ? hi.z : 0u; hi.w = real ? hi.w : 0u;
-        lo.x = real ? lo.x : 0u; lo.y = real ? lo.y : 0u; lo.z = real ? lo.z : 0u; lo.w = real ? lo.w : 0u;
-        if (it < 2 || unit_py(2) < kQRows) {
-            *reinterpret_cast<uint4*>(pb + lw0 + it * 4096) = hi;
-            *reinterpret_cast<uint4*>(pb + lw0 + it * 4096 + 2 * kQPlane) = lo;
+        hi.x = real ? hi.x : 0u; hi.y = real ? hi.y : 0u;
+        lo.x = real ? lo.x : 0u; lo.y = real ? lo.y : 0u;
+        if (it < MAXU - 1 || unit_py(MAXU - 1) < kQRows) {
+            *reinterpret_cast<uint2*>(pb + lw0 + it * 2048) = hi;
+            *reinterpret_cast<uint2*>(pb + lw0 + it * 2048 + 2 * kQPlane) = lo;
         }
     };
     auto weights_dma = [&](int ch, unsigned char* wb) {     // 36 pieces of 1 KiB; every wave issues exactly 5 (pieces 32..35 twice)
@@ -137,13 +145,23 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
     unsigned char* const wbuf0 = smem8 + 2 * kQPatch;
     // ---- fill the pipeline: item 0 staged synchronously (once per workgroup), item 1 requested
     Item cur{0, 0}, nx1{0, 0}, nx2{0, 0};
-    prefetch(cur);
+    {
+        const Req q0 = request(cur);
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) load_unit(q0, it);
+        load_norm(q0);
+    }
     weights_dma(0, wbuf0);
 #pragma unroll
     for (int it = 0; it < MAXU; ++it) convert(it, smem8);
     advance(nx1);
     nx2 = nx1;
-    prefetch(nx1);
+    {
+        const Req q1 = request(nx1);
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) load_unit(q1, it);
+        load_norm(q1);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     advance(nx2);
 
@@ -190,14 +208,17 @@ __global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs 
             _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) \
                 acc_c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur_][mt][0], fb[cur_][nt][0], acc_c[mt][nt], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0); }
+        const Req rq = request(nx2);                         // the item after next: each unit re-requested right behind its conversion
         TS2D_LOAD_FRAGS(0, 0)
         // (memory operations of an item: every use of a loaded register first, THEN the weight DMA: hipcc answers ANY use of a loaded
         //  register with s_waitcnt vmcnt(0) while a global_load_lds is in flight, and falls back to vmcnt(0) at control-flow joins)
-        TS2D_TAP(0, convert(0, pb_next);)
-        TS2D_TAP(1, convert(1, pb_next);)
-        TS2D_TAP(2, convert(2, pb_next); prefetch(nx2);)
-        TS2D_TAP(3, weights_dma(nx1.c, wb_next);)
-        TS2D_TAP(4, ) TS2D_TAP(5, ) TS2D_TAP(6, ) TS2D_TAP(7, ) TS2D_TAP(8, )
+        TS2D_TAP(0, convert(0, pb_next); load_unit(rq, 0);)
+        TS2D_TAP(1, convert(1, pb_next); load_unit(rq, 1);)
+        TS2D_TAP(2, convert(2, pb_next); load_unit(rq, 2);)
+        TS2D_TAP(3, convert(3, pb_next); load_unit(rq, 3);)
+        TS2D_TAP(4, convert(4, pb_next); load_unit(rq, 4); load_norm(rq);)
+        TS2D_TAP(5, weights_dma(nx1.c, wb_next);)
+        TS2D_TAP(6, ) TS2D_TAP(7, ) TS2D_TAP(8, )
 #undef TS2D_TAP
 #undef TS2D_LOAD_FRAGS
 #pragma unroll

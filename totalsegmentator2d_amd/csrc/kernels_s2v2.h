@@ -35,21 +35,6 @@ namespace ts2d {
 constexpr int kS2Threads = 512;
 constexpr int kS2PW = 66, kS2Slots = 17 * kS2PW, kS2Plane = kS2Slots * 16;      // patch: 17 rows x (33 even + 33 odd columns)
 
-// fp32 x 4 -> fp16 hi[4] + lo[4] (x = hi + lo to 22 bits): the 4-value form of split_hi_lo_8 (kernels_f16x3.h)
-__device__ __forceinline__ void split_hi_lo_4(const f32x4& v, uint2& hi, uint2& lo) {
-    unsigned h0, h1, l0, l1;
-    asm volatile(
-        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
-        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
-        "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)
-        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-    hi = uint2{h0, h1}; lo = uint2{l0, l1};
-}
-
 // Round 3: PERSISTENT workgroups.  In-kernel stamps of round 2 (profiles/r02_phase_stamps.txt, enc1.c0): of ~27 000 cycles per
 // two-chunk workgroup 8 800 were spent waiting for the first chunk's patch - one workgroup per CU (LDS), nothing else resident to
 // hide it, 16 384 workgroups per launch.  Now a workgroup (one per CU, fixed XCD lane and column tile as conv3x3_f16x3_qp) walks
