@@ -41,7 +41,8 @@ def main():
     shutil.copy(os.path.join(src, 'bench.json'), os.path.join(P, f'{tag}_bench.json'))
     shutil.copy(os.path.join(src, 'prof_kt', 'runc_kernel_stats.csv'), os.path.join(P, f'{tag}_kernel_stats.csv'))
     pj = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'pmc_traffic.py'), os.path.join(src, 'pmc_fetch', 'runc_counter_collection.csv'),
-                         os.path.join(src, 'pmc_write', 'runc_counter_collection.csv'), '3'], check=True, capture_output=True, text=True).stdout
+                         os.path.join(src, 'pmc_write', 'runc_counter_collection.csv'), '3', os.path.join(src, 'prof_kt', 'runc_kernel_stats.csv')],
+                        check=True, capture_output=True, text=True).stdout
     for name in ('pmc_traffic.json', f'{tag}_pmc_traffic.json'):
         open(os.path.join(P, name), 'w').write(pj)
     open(os.path.join(P, f'{tag}_sq_counters.txt'), 'w').write(sq_table(os.path.join(src, 'pmc_sq', 'runc_counter_collection.csv'), tag))
