@@ -103,6 +103,21 @@ def test_randomised_window_configurations_match_the_torch_pipeline():
         assert out.dtype == np.float16 and np.array_equal(out, ref), (t, feats, shape, patch, step, mirror, folds, order)
 
 
+def test_nonzero_mask_fills_holes_for_volumes_only():
+    """upstream's non-zero mask is binary_fill_holes(OR over channels of data != 0) on [Z, H, W].  With Z = 1 nothing is
+    enclosed (the 2-D path: an inner zero stays outside the mask); with Z > 1 an enclosed zero belongs to the mask."""
+    from scipy.ndimage import binary_fill_holes
+    from totalsegmentator2d_amd import preprocess as P
+    vol = np.ones((1, 5, 7, 7), np.float32)
+    vol[0, 2, 3, 3] = 0                                                   # a zero enclosed in 3-D
+    _, _, m3 = P.crop_to_nonzero(vol, return_mask=True)
+    assert m3[2, 3, 3] and np.array_equal(m3, binary_fill_holes(vol[0] != 0))
+    flat = np.ones((1, 1, 7, 7), np.float32)
+    flat[0, 0, 3, 3] = 0
+    _, _, m2 = P.crop_to_nonzero(flat, return_mask=True)
+    assert not m2[0, 3, 3] and np.array_equal(m2, binary_fill_holes(flat[0] != 0))      # (upstream's own call leaves it out, too)
+
+
 def test_normalisation_schemes_of_the_preprocessor():
     """SURVEY row A1, the branches beside the plain z-score: masked ZScoreNormalization (statistics inside the non-zero mask,
     the outside stays 0), CTNormalization (clip to the dataset percentiles, dataset mean / std), Rescale / RGB / No normalisation."""

@@ -67,8 +67,13 @@ def read_images(files: Sequence[str]) -> Tuple[np.ndarray, dict]:
 def crop_to_nonzero(data: np.ndarray, return_mask: bool = False):
     """``crop_to_nonzero``: bounding box of voxels that are non-zero in ANY channel.  ``return_mask``: also the non-zero mask inside
     the box - upstream writes it into the segmentation (``seg = where(nonzero_mask, 0, -1)``) and the masked normalisers use
-    ``seg >= 0``."""
+    ``seg >= 0``.  Upstream fills the holes of the mask (``create_nonzero_mask``: ``binary_fill_holes`` on the [Z, H, W] mask, default
+    3-D structure) - a no-op for the [C, 1, H, W] inputs of the 2-D path (with Z = 1 every voxel lies on the array's border, so no
+    background region is enclosed), applied here for Z > 1 so that a volume input is masked like upstream masks it [UPSTREAM-RECALL]."""
     nz = np.any(data != 0, axis=0)
+    if nz.ndim == 3 and nz.shape[0] > 1:
+        from scipy.ndimage import binary_fill_holes
+        nz = binary_fill_holes(nz)
     if not nz.any():
         bbox = [[0, s] for s in data.shape[1:]]
     else:
