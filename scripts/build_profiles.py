@@ -40,6 +40,14 @@ def main():
     P = os.path.join(ROOT, 'profiles')
     shutil.copy(os.path.join(src, 'bench.json'), os.path.join(P, f'{tag}_bench.json'))
     shutil.copy(os.path.join(src, 'prof_kt', 'runc_kernel_stats.csv'), os.path.join(P, f'{tag}_kernel_stats.csv'))
+    f16 = os.path.join(src, 'prof_kt_f16', 'runc_kernel_stats.csv')
+    if os.path.exists(f16):
+        with open(os.path.join(P, f'{tag}_kernel_stats_f16.csv'), 'w') as f:
+            f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --precision f16 --steps 2 --warmup 1 --no-cpu-baseline --no-other-modes --no-profile (3 forwards)\n')
+            f.write(open(f16).read())
+    hp = os.path.join(src, 'hbm_probe.txt')
+    if os.path.exists(hp):
+        shutil.copy(hp, os.path.join(P, f'{tag}_hbm_probe.txt'))
     pj = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'pmc_traffic.py'), os.path.join(src, 'pmc_fetch', 'runc_counter_collection.csv'),
                          os.path.join(src, 'pmc_write', 'runc_counter_collection.csv'), '3', os.path.join(src, 'prof_kt', 'runc_kernel_stats.csv')],
                         check=True, capture_output=True, text=True).stdout
@@ -56,7 +64,7 @@ def main():
                 seen.add(k); keep.append(l)
         hdr = ('# TS2D_DBG=256 python scripts/gpu_ops_only.py split: shader-clock cycles of wave 0 per workgroup between in-kernel stamps (kernels.h TS2D_STAMP_AT)\n'
                '# conv3x3_upc (decN.c0, N<=4): [0]/[1] phase-1 staging / MFMAs (+ wait at the next barrier), [2]/[3] phase 2, [4] bias + stores, [5]/[6] barriers\n'
-               '# conv3x3_f16x3_p / conv3x3s2_v2: [0] barrier wait after staging, [1] MFMAs + barrier, [2] weight-load issue, [4] patch conversion, [6] weight store (p), [3] last MFMAs, [5] epilogue\n'
+               '# conv3x3s2_v2 (round 4): [3] accumulate + merge, [1] top barrier, [2] wait for the raw patch, [6] conversion, [0] DMA wait + barrier, [5] the nine taps (+ one patch load each), [4] tile epilogue\n'
                '# conv3x3_f16x3_q: [0] wait at the end-of-chunk barrier, [1] chunk body, [3]-[5] epilogue\n')
         open(os.path.join(P, f'{tag}_phase_stamps.txt'), 'w').write(hdr + ''.join(reversed(keep)))
     j = json.load(open(os.path.join(P, f'{tag}_bench.json')))

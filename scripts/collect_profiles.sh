@@ -15,6 +15,7 @@ timeout -k 10 250 rocprofv3 --kernel-trace --stats $F -d "$O/prof_kt" -o runc --
 timeout -k 10 250 rocprofv3 --kernel-trace --pmc FETCH_SIZE $F -d "$O/pmc_fetch" -o runc -- python3 "$R/bench.py" $A > "$O/pmc_fetch.log" 2>&1
 timeout -k 10 250 rocprofv3 --kernel-trace --pmc WRITE_SIZE $F -d "$O/pmc_write" -o runc -- python3 "$R/bench.py" $A > "$O/pmc_write.log" 2>&1
 timeout -k 10 250 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY $F -d "$O/pmc_sq" -o runc -- python3 "$R/bench.py" $A > "$O/pmc_sq.log" 2>&1
+timeout -k 10 250 rocprofv3 --kernel-trace --stats $F -d "$O/prof_kt_f16" -o runc -- python3 "$R/bench.py" $A --precision f16 > "$O/prof_kt_f16.log" 2>&1
 cd "$R"
 TS2D_DBG=256 timeout -k 10 200 python3 scripts/gpu_ops_only.py split > "$O/phase_stamps.txt" 2>&1 || true
 (cd scripts/probes && timeout -k 10 120 ./hbm_probe > "$O/hbm_probe.txt" 2>&1) || true

@@ -1315,7 +1315,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 ua.B = B; ua.H = Ht; ua.W = Wt; ua.Cout = op.cout;
                 ua.tiles_x = Wt / 32; ua.tiles_y = Ht / 16; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y; ua.n_ctiles = op.cout / 64;
                 ua.lg_nct = ilog2(ua.n_ctiles); ua.lg_tx = ilog2(ua.tiles_x); ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
-                ua.slope = a.leaky_slope;
+                ua.slope = a.leaky_slope; ua.dbg = e->dbg;
                 static std::atomic<uint64_t> doneh2p{0};
                 HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h2<4, false>), doneh2p));
                 hipLaunchKernelGGL((conv3x3_upc_h2<4, false>), dim3((ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles), dim3(kBlock), kUh2Lds, st, ua);

@@ -20,7 +20,7 @@
 // Measured (gpurun r2 qp1/qp2): 64 -> 64 at level 1 0.93 (conv3x3_f16x3_p) -> 0.84-0.89 ms, 128 -> 128 0.83 -> 0.78, 256 / 512 channels
 // unchanged (0.76 / 0.74): the gain is the per-tile fill and drain, which weighs less the more chunks a tile has.
 //
-// Round 4: the raw patch loads.  In-kernel stamps (profiles/r04_phase_stamps.txt): wave 0 spent 2.3 k of an item's ~9.5 k cycles at the
+// Round 4: the raw patch loads.  In-kernel stamps (profiles/r04_experiments.txt): wave 0 spent 2.3 k of an item's ~9.5 k cycles at the
 // ISSUE of the six patch loads of tap 2.  Each of those wave instructions touched 32 different 128-byte lines (32 pixels x 2 lanes x
 // 16 bytes); the address path retires about a line per cycle, and all eight waves queued their loads in one burst.  Now a staging
 // unit is ONE 16-byte quarter of a pixel's 64-byte chunk slice - four lanes per pixel, a wave instruction covers 16 pixels = 16

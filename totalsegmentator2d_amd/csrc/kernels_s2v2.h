@@ -15,7 +15,7 @@
 //   * the weight block of a (chunk, column tile) is stored in HBM in LDS order and copied linearly.
 // Arithmetic as in kernels_f16x3.h (split: hi/lo fp16, 3 products, fresh accumulator per chunk; f16: one product).
 //
-// Round 4.  In-kernel stamps (profiles/r04_phase_stamps.txt, enc2.c0, per item of 6.9 k cycles of MFMAs): 5.2 k cycles between the
+// Round 4.  In-kernel stamps (profiles/r04_s2v2_stamps.txt, enc2.c0, per item of 6.9 k cycles of MFMAs): 5.2 k cycles between the
 // conversion barrier and the first MFMA - the wave sat at the ISSUE of the next item's ten patch loads.  Each of those wave
 // instructions touched 32 different 128-byte lines (32 pixels x 2 lanes x 16 bytes) and the address path retires about one line per
 // cycle: 80 instructions x ~64 cycles per item and CU, all eight waves queueing at once in front of their MFMAs.  Now (fp32 storage):

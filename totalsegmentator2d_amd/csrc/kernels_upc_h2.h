@@ -205,12 +205,20 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_upc_h2(const UpcArgs a) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight DMA has landed (nothing else is in flight here)
             __syncthreads();
-            if (ch + 1 < nch) prefetch(ch + 1);
+            // (round 4: the next chunk's ten patch loads ride one per tap behind the first ten taps' MFMAs instead of being issued in
+            //  one burst in front of them - each wave instruction touches 32 lines, see kernels_s2v2.h)
+            const bool burst = a.dbg & 2048;                   // diagnostic A/B (TS2D_DBG=2048): the round-3 order
+            if (burst && ch + 1 < nch) prefetch(ch + 1);
+            const bool more = ch + 1 < nch && !burst;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
+                    if (ks * 9 + tap < 2 * MAXU && more) {
+                        const int u_ = (ks * 9 + tap) >> 1, l_ = (ks * 9 + tap) & 1;
+                        pv[u_][l_] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[u_] + 32 * l_, (ch + 1) * 64, 0);
+                    }
                     const int ky = tap / 3, kx = tap - 3 * ky;
                     const int toff = ks * 2 * kUq2Plane + ky * kUq2Pitch * 16 + tofs[kx];
                     half8 ah[MT], bh[NT];
