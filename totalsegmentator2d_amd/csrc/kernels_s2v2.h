@@ -33,7 +33,12 @@
 namespace ts2d {
 
 constexpr int kS2Threads = 512;
-constexpr int kS2PW = 66, kS2Slots = 17 * kS2PW, kS2Plane = kS2Slots * 16;      // patch: 17 rows x (33 even + 33 odd columns)
+constexpr int kS2PW = 66, kS2Slots = 17 * kS2PW;      // patch: 17 rows x (33 even + 33 odd columns)
+// plane stride = 64 mod 128 bytes: the four lanes of a pixel write 8 bytes each into two planes (ds_write_b64, fp32 storage) - with the
+// planes 16 dwords apart in the bank map a 16-lane group covers 32 distinct banks (at 32 mod 128 bytes, the unpadded stride, two of its
+// four pixels collided: 16-19 % LDS bank conflicts in the round-4 counters); the fragment reads are conflict-free at any alignment
+constexpr int kS2Plane = (kS2Slots + 2) * 16;
+static_assert(kS2Plane % 128 == 64, "plane stride of conv3x3s2_v2");
 
 // Round 3: PERSISTENT workgroups.  In-kernel stamps of round 2 (profiles/r02_phase_stamps.txt, enc1.c0): of ~27 000 cycles per
 // two-chunk workgroup 8 800 were spent waiting for the first chunk's patch - one workgroup per CU (LDS), nothing else resident to
