@@ -17,6 +17,7 @@
 #include "kernels_upq.h"
 #include "kernels_upc_h.h"
 #include "kernels_upc_h2.h"
+#include "kernels_hq.h"
 #include "kernels_sw.h"
 #include "kernels_project.h"
 
@@ -138,6 +139,7 @@ struct ts2d_engine {
     int upq_min = 256;            // "upq_min": least coarse channel count served by conv3x3_upq
     bool use_h2 = true;           // "h2": 16-bit plain C -> C blocks on 16 x 32 tiles (0: conv3x3_h32); "h2_min": least channel count
     int h2_min = 64;
+    bool use_hq = false;          // "hq": those blocks as one persistent pipelined workgroup per CU (kernels_hq.h; 0: conv3x3_h2)
     bool use_uh2 = true;          // "uh2": 16-bit composed block on 16 x 32 tiles (0: conv3x3_upc_h)
     bool use_up0 = true;          // "up0": dedicated persistent kernel of the level-0 composed block (0: conv3x3_upc<32>)
     int u0seg = 0;                // "u0seg": tiles per workgroup segment of conv3x3_up0 (0: chosen from the grid; tests force segments that end inside an image)
@@ -1306,7 +1308,24 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const bool h2 = split && f16 && stride == 1 && e->use_h2 && op.cout % 64 == 0 && op.skip < 0 && ct_total(op) % 32 == 0 && g.lgNIMG == 0 && img32 &&
                             Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr && lg_exact(Wt / 32) >= 0 && lg_exact((Wt / 32) * (Ht / 16)) >= 0 &&
                             lg_exact(op.cout / 64) >= 0 && ct_total(op) >= e->h2_min;
-            if (h2) {
+            if (h2 && e->use_hq) {
+                // 16-bit mode, plain C -> C block: the persistent double-buffered pipeline of conv3x3_f16x3_qp on 32-channel chunks (kernels_hq.h)
+                ca.wph = wts + op.dev_wp;
+                ca.tiles_x = Wt / 32; ca.tiles_y = Ht / 16; ca.n_mtiles = B * ca.tiles_x * ca.tiles_y;
+                ca.lg_tx = lg_exact(ca.tiles_x); ca.lg_tpi = lg_exact(ca.tiles_x * ca.tiles_y);
+                const int gridq = (ca.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
+                const int gridp = std::min(gridq, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));     // one persistent workgroup per CU
+                static std::atomic<uint64_t> donehq{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_hq<0>), donehq));
+                switch ((e->dbg >> 12) & 15) {
+#define TS2D_HQ(A_) case A_: { static std::atomic<uint64_t> d_{0}; HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_hq<A_>), d_)); \
+                        hipLaunchKernelGGL(conv3x3_hq<A_>, dim3(gridp), dim3(kQThreads), kHqLds, st, ca); } break;
+                    TS2D_HQ(1) TS2D_HQ(2) TS2D_HQ(4) TS2D_HQ(8) TS2D_HQ(6) TS2D_HQ(14)
+#undef TS2D_HQ
+                    default: hipLaunchKernelGGL(conv3x3_hq<0>, dim3(gridp), dim3(kQThreads), kHqLds, st, ca);
+                }
+                le = hipGetLastError(); prof_kernel(e, "conv3x3_hq");
+            } else if (h2) {
                 // 16-bit mode, plain C -> C block on 16 x 32 tiles: the skip phase of conv3x3_upc_h2 (four M tiles per wave, weights by LDS-DMA)
                 UpcArgs ua{};
                 ua.xs = src.data; ua.scs = src.scale; ua.shs = src.shift; ua.Cs = src.C;
@@ -1475,7 +1494,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
     if (!e || !name) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_option: null argument");
     struct B { const char* n; bool* p; };
     struct I { const char* n; int* p; int lo, hi; };
-    const B bools[] = {{"h32", &e->use_h32}, {"one", &e->use_one}, {"s2v2", &e->use_s2v2}, {"q", &e->use_q}, {"h2", &e->use_h2}, {"uh2", &e->use_uh2},
+    const B bools[] = {{"h32", &e->use_h32}, {"one", &e->use_one}, {"s2v2", &e->use_s2v2}, {"q", &e->use_q}, {"h2", &e->use_h2}, {"hq", &e->use_hq}, {"uh2", &e->use_uh2},
                        {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}};
     const I ints[] = {{"upq_min", &e->upq_min, 0, 1 << 20}, {"h2_min", &e->h2_min, 0, 1 << 20}, {"u0seg", &e->u0seg, 0, 1 << 20}};
     bool found = false;
@@ -1484,7 +1503,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
         if (value < i.lo || value > i.hi) return fail(TS2D_ERR_INVALID, "option %s = %d out of range [%d, %d]", name, value, i.lo, i.hi);
         *i.p = value; found = true;
     }
-    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0)", name);
+    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min hq uh2 up0 u0seg upq upq_min upc res fuse0)", name);
     e->ws_precision = -1;         // which ops compose (and with it the activation plan) depends on the options: re-plan at the next reserve / forward
     return TS2D_OK;
 }
