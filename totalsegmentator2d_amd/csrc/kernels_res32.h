@@ -1,19 +1,22 @@
 // Level-0 block: Conv2d 3x3 stride 1, 32 -> 32 channels (enc0.c1 / dec0.c1 of the canonical net, 512x512 pixels per
 // slice - the layers that sit between the HBM and the MFMA roof), as a PERSISTENT kernel with the whole layer's weights RESIDENT
-// in LDS (32 x 32 x 9 x (hi + lo) fp16 = 36 KB) and ONE K step covering all 32 input channels:
-//   * v_mfma_f32_16x16x32_f16 (K = 32 = Cin).  On this chip the 16x16x32 shape holds a higher clock than 32x32x16 under load
-//     (scripts/probes/mfma_shape_probe.hip: +13..15 % FLOP/s at equal cycles per FLOP).  The product is issued TRANSPOSED,
-//     D[cout][pixel] = W^T[cout][ci] * X[ci][pixel]: a lane then holds 4 consecutive output channels of one pixel - one 16-byte NHWC
-//     store per 16x16 block instead of four 4-byte ones.
+// in LDS (32 x 32 x 9 x (hi + lo) fp16 = 36 KB):
+//   * v_mfma_f32_32x32x16_f16, D[pixel][cout]: a wave owns 2 rows of 32 pixels x the 32 output channels (two k-steps per tap, 108
+//     MFMAs per tile in split mode), epilogue as conv3x3_f16x3_qp: lane = channel, 4-byte stores (32 lanes = one pixel's whole
+//     128-byte record), statistics summed in registers with one cross-half add.
+//     (Rounds 2-3 issued v_mfma_f32_16x16x32_f16 TRANSPOSED, D[cout][pixel], for 16-byte stores: that shape holds the SIMD's vector
+//      issue for 8 of its 16 cycles - the partner workgroup's conversion / epilogue ran at 8.4 cycles per VALU instruction - and its
+//      epilogue needed 64 DPP adds per tile for the 16-lane statistics reduction.  Same-process A/B, round 4
+//      (profiles/r04_experiments.txt): 1.16 -> 1.07 ms per launch in split mode, whole step -0.15 ms; equal in the 16-bit mode.)
 //   * one staging phase and two barriers per 256-pixel tile (the generic kernel: two 16-channel chunks, each with its own weight
 //     staging and barrier pair); no weight traffic after the first tile of a workgroup.
 //   * the next tile's raw patch is prefetched into registers across the tile boundary (behind the MFMA phase and the epilogue).
 //   * a workgroup owns a SEGMENT of consecutive tiles of one image (column by column: consecutive tiles share their halo
 //     rows through L2).
-//   * LDS images are "k-group major": plane[g][pixel] of 16-byte slots (g = the 8-channel group a lane feeds to the MFMA),
-//     plane stride a multiple of 256 B.  A ds_read_b128 lane group (lanes {0-3,12-15} of one g + {4-11} of the next) then covers
-//     16 distinct slots of the 256-byte bank row with NO swizzle arithmetic, and every fragment address is lane base + immediate.
-// Arithmetic: split mode (NP = 3): x = hi + lo, w = whi + wlo, products wlo*xhi + whi*xlo + whi*xhi, fp32 accumulation over the
+//   * LDS images are "k-group major": plane[g][pixel] of 16-byte slots (g = the 8-channel group (k-step, lane half) a lane feeds to
+//     the MFMA), plane stride a multiple of 256 B: the 32 lanes of a lane half read 32 consecutive slots - conflict-free
+//     ds_read_b128 at any alignment - and every fragment address is lane base + immediate.
+// Arithmetic: split mode (NP = 3): x = hi + lo, w = whi + wlo, products xlo*whi + xhi*wlo + xhi*whi, fp32 accumulation over the
 // 9 taps x 32 channels of the layer (288-term chains; the generic kernel sums two 144-term chunks).  f16 mode (NP = 1): one product.
 #pragma once
 #include "kernels_f16x3.h"
@@ -51,7 +54,7 @@ constexpr int kResPW = 34, kResP = 340, kResPS = 352 * 16;      // patch 10 x 34
 // (TRANSPOSED product: rows = channels, so that a lane holds 4 consecutive channels of one pixel = half a 16-byte LDS slot),
 // normalises with the scale / shift of a statistics-only pass, applies LeakyReLU, zeroes what lies outside the image (the padding of
 // THIS conv), splits hi / lo and writes the same k-group-major planes the MFMA phase reads.  Cost per tile and wave: 27 fp32 MFMAs of
-// 64 cycles beside the 216 (x 16 cycles) of the block itself; saved: 4.3 GB of HBM traffic per 64-slice step.
+// 64 cycles beside the 108 (x 32 cycles) of the block itself; saved: 4.3 GB of HBM traffic per 64-slice step.
 template <typename ST, int NP, bool FUSE = false>
 __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
     constexpr int NPP = NP == 3 ? 2 : 1;                   // fp16 parts per value (hi, lo)
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15, g = lane >> 4;                // MFMA lane roles: row/column index, k-group
+    const int r = lane & 31, h = lane >> 5;                // MFMA lane roles: row / column index, k half
 
     // ---- work list: segment s = tiles [s * seg, (s + 1) * seg), tiles numbered column by column inside an image
     //      (t = (n * tiles_x + txi) * tiles_y + tyi); seg divides tiles_x * tiles_y, so a segment lies in one image.
@@ -85,17 +88,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
         }
     }
     unsigned char* sP = smem8 + WB;                        // patch planes [part][g][pixel] x 16 B
-    // cross-wave statistics scratch: 96-byte pieces (sums, squares, pivots of 8 channels) in the 12 unused slots at the end of
-    // each patch plane (split mode: the two workgroups of a CU use all 160 KiB), or behind the planes (f16 mode)
-    auto scratch = [&](int ww, int gg) -> float* {
-        if (NPP == 2) return reinterpret_cast<float*>(sP + (2 * ww + (gg >> 1)) * kResPS + kResP * 16 + (gg & 1) * 96);
-        return reinterpret_cast<float*>(sP + NPP * 4 * kResPS + (ww * 4 + gg) * 96);
-    };
-
     // ---- staging plan.  Unit (it): pixel p = 64 it + 16 w + (lane & 7) + 8 (lane >> 5), channel group sg = (lane >> 3) & 3:
     //      one wave instruction covers 16 whole pixels (every byte of their 128-byte records), 8 consecutive lanes write 8
     //      consecutive 16-byte slots of one plane (conflict-free ds_write_b128).
     const int sg = (lane >> 3) & 3, pl = (lane & 7) + 8 * (lane >> 5);
+    // cross-wave statistics scratch: per wave and 16-channel half [3 = S, Q, K][16 channels] floats = 192 bytes = the 12 unused slots at the
+    // end of ONE patch plane (split mode: the two workgroups of a CU use all 160 KiB; wave ww: planes 2 ww, 2 ww + 1), or behind the planes (f16 mode)
+    auto scratch32 = [&](int ww, int half) -> float* {
+        if (NPP == 2) return reinterpret_cast<float*>(sP + (2 * ww + half) * kResPS + kResP * 16);
+        return reinterpret_cast<float*>(sP + NPP * 4 * kResPS + (ww * 2 + half) * 192);
+    };
     unsigned rel[FUSE ? 1 : NU];          // byte offset of the unit's 8 channels relative to the patch origin (ty0 - 1, tx0 - 1)
     unsigned emask = 0;        // per unit 4 bits: patch row 0 / row 9 / column 0 / column 33 (the padding candidates)
     bool last_unit = false;
@@ -184,15 +186,10 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
     prefetch(txi, tyi);
 
     // ---- lane constants of the MFMA phase and the epilogue
-    const int wbase = g * 512 + j * 16;                                    // weight fragment: + ((tap * NPP + part) * 4) * 512 + cb * 256
-    const int pbase = WB + g * kResPS + (2 * w * kResPW + j) * 16;        // patch fragment: + part * 4 * PS + ((pb >> 1) + dy) * 34 * 16 + (16 (pb & 1) + dx) * 16
-    float bv[2][4];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bv[cb][i] = a.bias[cb * 16 + 4 * g + i];
+    const int wb32 = h * 512 + r * 16;                                     // weight fragment: + ((tap * NPP + part) * 4 + 2 ks) * 512
+    const int pb32 = WB + h * kResPS + (2 * w * kResPW + r) * 16;          // patch fragment: + (part * 4 + 2 ks) * PS + ((row + dy) * 34 + dx) * 16
+    const float bv32 = a.bias[r];
     const float oscale = *a.oscale;
-    const unsigned vst = (unsigned)((j * 32 + 4 * g) * (int)sizeof(ST));   // store: lane part of the byte offset
     const _Float16 slope_h = (_Float16)a.slope;
     const unsigned slope2 = (unsigned)__builtin_bit_cast(unsigned short, slope_h) * 0x10001u;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.dst) + (size_t)n * img_bytes, 0, (int)img_bytes, 0x00020000);
@@ -299,127 +296,74 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
         if (nty == a.tiles_y) { nty = 0; ntx = txi + 1; }
         if (t + 1 < t1) prefetch(ntx, nty);
 
-        // ---- 9 taps x (2 channel blocks x 4 pixel blocks) x NP products
-        f32x4 acc[2][4];
+        // ---- 9 taps x 2 k-steps x 2 rows x NP products (32 pixels x 32 channels x 16)
+        f32x16 acc[2];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap - 3 * dy;
-            half8 fw[2][NPP], fx[4][NPP];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int pt2 = 0; pt2 < NPP; ++pt2)
-                    fw[cb][pt2] = *reinterpret_cast<const half8*>(smem8 + wbase + ((tap * NPP + pt2) * 4) * 512 + cb * 256);
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-                for (int pt2 = 0; pt2 < NPP; ++pt2)
-                    fx[pb][pt2] = *reinterpret_cast<const half8*>(smem8 + pbase + pt2 * 4 * kResPS + (((pb >> 1) + dy) * kResPW + 16 * (pb & 1) + dx) * 16);
-            if constexpr (NP == 3) {
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb][1], fx[pb][0], acc[cb][pb], 0, 0, 0);
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                    for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb][0], fx[pb][1], acc[cb][pb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[cb][0], fx[pb][0], acc[cb][pb], 0, 0, 0);
-        }
+        // the fragments of tap t + 1 are read while the MFMAs of tap t run: two register sets, one scheduling region per tap (left to
+        // itself hipcc put every ds_read_b128 pair directly in front of the MFMA that consumes it)
+        half8 fw[2][2][NPP], fx[2][2][2][NPP];                                // [set][k-step][part], [set][row][k-step][part]
+#define TS2D_R32_LOAD(SET, TAP) { constexpr int dy_ = (TAP) / 3, dx_ = (TAP) - 3 * dy_; \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int pt2 = 0; pt2 < NPP; ++pt2) { \
+                fw[SET][ks][pt2] = *reinterpret_cast<const half8*>(smem8 + wb32 + (((TAP) * NPP + pt2) * 4 + 2 * ks) * 512); \
+                _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) \
+                    fx[SET][mt][ks][pt2] = *reinterpret_cast<const half8*>(smem8 + pb32 + (pt2 * 4 + 2 * ks) * kResPS + ((mt + dy_) * kResPW + dx_) * 16); } }
+#define TS2D_R32_TAP(TAP) { constexpr int c_ = (TAP) & 1; \
+            if constexpr ((TAP) + 1 < 9) TS2D_R32_LOAD(c_ ^ 1, (TAP) + 1) \
+            if constexpr (NP == 3) { \
+                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) \
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[c_][mt][ks][NPP - 1], fw[c_][ks][0], acc[mt], 0, 0, 0); \
+                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) \
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[c_][mt][ks][0], fw[c_][ks][NPP - 1], acc[mt], 0, 0, 0); } \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) \
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[c_][mt][ks][0], fw[c_][ks][0], acc[mt], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0); }
+        TS2D_R32_LOAD(0, 0)
+        TS2D_R32_TAP(0) TS2D_R32_TAP(1) TS2D_R32_TAP(2) TS2D_R32_TAP(3) TS2D_R32_TAP(4) TS2D_R32_TAP(5) TS2D_R32_TAP(6) TS2D_R32_TAP(7) TS2D_R32_TAP(8)
+#undef TS2D_R32_TAP
+#undef TS2D_R32_LOAD
         __builtin_amdgcn_s_setprio(0);
         TS2D_STAMP_AT(a.prof, 2)
 
-        // ---- epilogue: lane = pixel j of block pb, channels 16 cb + 4 g .. + 3: one 16-byte (fp16: 8-byte) store per block
-        f32x4 ov[2][4];
+        // ---- epilogue: C/D map of the 32x32 MFMA: column = lane & 31 (channel), row = (i & 3) + 8 (i >> 2) + 4 h (pixel of the row)
         {
-            float ss[2][4], qq[2][4], kv[2][4];            // shifted (sum, sum of squares) of this lane's 4 pixels per channel + their pivot:
-#pragma unroll                                            // the stored value of pixel 0 of the wave's first 16-pixel block (kernels.h)
-            for (int cb = 0; cb < 2; ++cb)
+            const float kv = stat_pivot(round_act<ST>(__builtin_fmaf(acc[0][0], oscale, bv32)));      // shifted statistics (kernels.h)
+            float s = 0.f, q = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ss[cb][i] = 0.f; qq[cb][i] = 0.f;
-                    float v0 = __builtin_fmaf(acc[cb][0][i], oscale, bv[cb][i]);
-                    if constexpr (sizeof(ST) != 4) v0 = (float)(_Float16)v0;
-                    kv[cb][i] = __shfl(v0, lane & 48);
-                }
-            const unsigned tile_off = (unsigned)((((tyi * 8 + 2 * w) * a.W + txi * 32) * 32) * (int)sizeof(ST));      // scalar
+            for (int mt = 0; mt < 2; ++mt) {
+                const unsigned voff = (unsigned)(((((tyi * 8 + 2 * w + mt) * a.W + txi * 32 + 4 * h) * 32) + r) * (int)sizeof(ST));
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    const unsigned soff = tile_off + (unsigned)((((pb >> 1) * a.W + 16 * (pb & 1)) * 32 + cb * 16) * (int)sizeof(ST));
-                    f32x4 v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[cb][pb][i], oscale, bv[cb][i]);
-                    // gfx950 hazard (found with this kernel): a VALU write to the data registers of a 128-bit buffer store two
-                    // instructions behind it reaches the stored data (last dword, lanes 12-15 of each lane row) - hipcc's one
-                    // wait state is not enough, and with an SGPR soffset it inserts none.  The offset therefore rides in the VGPR
-                    // and the stored vectors stay live (asm use below) until the end of the tile.
-                    if constexpr (sizeof(ST) == 4) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsd, vst + soff, 0, 0);
-                    } else {
-                        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        half4 hv;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { hv[i] = (_Float16)v[i]; v[i] = (float)hv[i]; }      // statistics of what is stored
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rsd, vst + soff, 0, 0);
-                    }
-                    ov[cb][pb] = v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { const float d = v[i] - kv[cb][i]; ss[cb][i] += d; qq[cb][i] = __builtin_fmaf(d, d, qq[cb][i]); }
-                }
-            // sum over the 16 pixels of the lane row (DPP row rotations: every lane of the row ends up with the total)
-            float* sc4 = scratch(w, g);
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float s = ss[cb][i], q = qq[cb][i];
-#define TS2D_ROR_ADD(X, N) X += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, X), 0x120 + N, 0xF, 0xF, true))
-                    TS2D_ROR_ADD(s, 8); TS2D_ROR_ADD(q, 8); TS2D_ROR_ADD(s, 4); TS2D_ROR_ADD(q, 4);
-                    TS2D_ROR_ADD(s, 2); TS2D_ROR_ADD(q, 2); TS2D_ROR_ADD(s, 1); TS2D_ROR_ADD(q, 1);
-#undef TS2D_ROR_ADD
-                    ss[cb][i] = s; qq[cb][i] = q;
-                }
-                if (j == 0) {                              // 4 lanes per wave (g = 0..3): channels 16 cb + 4 g + i
-                    *reinterpret_cast<f32x4*>(sc4 + cb * 12) = f32x4{ss[cb][0], ss[cb][1], ss[cb][2], ss[cb][3]};
-                    *reinterpret_cast<f32x4*>(sc4 + cb * 12 + 4) = f32x4{qq[cb][0], qq[cb][1], qq[cb][2], qq[cb][3]};
-                    *reinterpret_cast<f32x4*>(sc4 + cb * 12 + 8) = f32x4{kv[cb][0], kv[cb][1], kv[cb][2], kv[cb][3]};
+                for (int i = 0; i < 16; ++i) {
+                    const float v = __builtin_fmaf(acc[mt][i], oscale, bv32);
+                    buffer_store_act<ST>(v, rsd, voff + (unsigned)((((i & 3) + 8 * (i >> 2)) * 32) * (int)sizeof(ST)), 0);
+                    const float d = round_act<ST>(v) - kv;                          // statistics of what is stored
+                    s += d; q = __builtin_fmaf(d, d, q);
                 }
             }
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if (h == 0) { float* sc = scratch32(w, r >> 4) + (r & 15); sc[0] = s; sc[16] = q; sc[32] = kv; }
         }
         TS2D_STAMP_AT(a.prof, 3)
         lds_barrier();                                     // every wave is done with the patch; the scratch is complete (stores in flight)
         // tile partial (fixed order over the 4 waves, rebased onto wave 0's pivot).  FUSE: by wave 3, which has one M tile less to
         // recompute in the next tile's first phase (the other waves would wait for wave 0 at the next barrier)
         if (FUSE ? (tid >= 192 && tid < 224) : tid < 32) {
-            const int co = tid & 31, cb = co >> 4, gg = (co >> 2) & 3, i = co & 3;
-            const float* s0 = scratch(0, gg) + cb * 12 + i;
-            f32x4 acc4 = f32x4{s0[0], s0[4], s0[8], 64.f};
+            const int co = tid & 31, c = co & 15;
+            const float* s0 = scratch32(0, co >> 4);
+            f32x4 acc4 = f32x4{s0[c], s0[16 + c], s0[32 + c], 64.f};
 #pragma unroll
             for (int ww = 1; ww < 4; ++ww) {
-                const float* sw_ = scratch(ww, gg) + cb * 12 + i;
-                const float d = sw_[8] - acc4[2];
-                acc4[1] += sw_[4] + d * (2.f * sw_[0] + 64.f * d);
-                acc4[0] += sw_[0] + 64.f * d;
+                const float* sw_ = scratch32(ww, co >> 4);
+                const float d = sw_[32 + c] - acc4[2];
+                acc4[1] += sw_[16 + c] + d * (2.f * sw_[c] + 64.f * d);
+                acc4[0] += sw_[c] + 64.f * d;
                 acc4[3] += 64.f;
             }
             *reinterpret_cast<f32x4*>(a.part + (((size_t)n * tpi + (t - n * tpi)) * 32 + co) * 4) = acc4;
         }
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) asm volatile("" :: "v"(ov[cb][pb]));      // store data registers untouched up to here
         txi = ntx; tyi = nty;
         TS2D_STAMP_AT(a.prof, 4)
     }
