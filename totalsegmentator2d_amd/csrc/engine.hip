@@ -17,8 +17,6 @@
 #include "kernels_upq.h"
 #include "kernels_upc_h.h"
 #include "kernels_upc_h2.h"
-#include "kernels_hq.h"
-#include "kernels_s2q.h"
 #include "kernels_sw.h"
 #include "kernels_project.h"
 
@@ -80,8 +78,6 @@ struct Op {
                                   // (conv3x3_f16x3_qp; stride-1 split_ok convs)
     bool s2v2_ok = false;         // stride-2 block: 512-thread kernel of kernels_s2v2.h
     size_t dev_w2 = 0;            // offset (floats) of its weight image [chunk16][column tile][tap][hi,lo][h][column][8 halves]
-    bool s2q_ok = false;          // stride-2 block with 128-column tiles: pipelined kernel of kernels_s2q.h
-    size_t dev_w2q = 0;           // its weight image [chunk8][column tile 128][k-step 5][hi,lo][h = tap & 1][column][8 halves] (k-step 4, h = 1: zeros)
     int bn2 = 0;                  // its column tile (128 or 64)
     bool res_ok = false;          // 32 -> 32 stride-1 block: resident-weight persistent kernel (kernels_res32.h)
     size_t dev_wres = 0;          // offset (floats) of its weight image [tap][hi,lo][g][cout][8 halves]
@@ -142,8 +138,6 @@ struct ts2d_engine {
     int upq_min = 256;            // "upq_min": least coarse channel count served by conv3x3_upq
     bool use_h2 = true;           // "h2": 16-bit plain C -> C blocks on 16 x 32 tiles (0: conv3x3_h32); "h2_min": least channel count
     int h2_min = 64;
-    bool use_s2q = true;          // "s2q": stride-2 blocks with 128-column tiles on the pipelined kernel (kernels_s2q.h; 0: conv3x3s2_v2<128>)
-    bool use_hq = false;          // "hq": those blocks as one persistent pipelined workgroup per CU (kernels_hq.h; 0: conv3x3_h2)
     bool use_uh2 = true;          // "uh2": 16-bit composed block on 16 x 32 tiles (0: conv3x3_upc_h)
     bool use_up0 = true;          // "up0": dedicated persistent kernel of the level-0 composed block (0: conv3x3_upc<32>)
     int u0seg = 0;                // "u0seg": tiles per workgroup segment of conv3x3_up0 (0: chosen from the grid; tests force segments that end inside an image)
@@ -272,7 +266,6 @@ int build_program(ts2d_engine* e) {
             if (op.stride == 2 && ct % 16 == 0 && op.cout % 64 == 0) {
                 op.s2v2_ok = true; op.bn2 = op.cout % 128 == 0 ? 128 : 64;
                 op.dev_w2 = wo; wo = align_up(wo + (size_t)ct * 9 * op.cout, 64);
-                if (op.cout % 128 == 0) { op.s2q_ok = true; op.dev_w2q = wo; wo = align_up(wo + (size_t)(ct / 8) * (op.cout / 128) * (kSqWts / 4), 64); }
             }
             if (op.stride == 1 && ct == 32 && op.cout == 32) {      // resident image of the 32 -> 32 block: [tap][hi,lo][g][cout][8 halves]
                 op.res_ok = true;
@@ -449,12 +442,6 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                                 const size_t blk = ((size_t)(ci / 16) * (co_n / bn2) + co / bn2) * (9 * 2 * 2 * bn2 * 8);
                                 w2[blk + ((((size_t)tap * 2 + 0) * 2 + (ci % 16) / 8) * bn2 + co % bn2) * 8 + ci % 8] = hi;
                                 w2[blk + ((((size_t)tap * 2 + 1) * 2 + (ci % 16) / 8) * bn2 + co % bn2) * 8 + ci % 8] = lo;
-                            }
-                            if (op.s2q_ok) {
-                                uint16_t* wq = reinterpret_cast<uint16_t*>(out + op.dev_w2q);
-                                const size_t blk = ((size_t)(ci / 8) * (co_n / 128) + co / 128) * (kSqWts / 2);
-                                wq[blk + ((((size_t)(tap >> 1) * 2 + 0) * 2 + (tap & 1)) * 128 + co % 128) * 8 + ci % 8] = hi;
-                                wq[blk + ((((size_t)(tap >> 1) * 2 + 1) * 2 + (tap & 1)) * 128 + co % 128) * 8 + ci % 8] = lo;
                             }
                             const int chunk = ci / 8, cc = (tap & 1) * 8 + ci % 8, bn = co_n % 64 == 0 ? 64 : 32;
                             uint16_t* rec = d + ((((size_t)chunk * (co_n / bn) + co / bn) * 5 + tap / 2) * bn + co % bn) * 32;
@@ -1212,29 +1199,6 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 // stride-2 block on full 8 x 32 output tiles: one 512-thread workgroup per CU, up to 128 output columns
                 ca.n_ctiles = op.cout / op.bn2; ca.lg_nct = lg_exact(ca.n_ctiles);
                 ca.wph = wts + op.dev_w2; ca.oscale = wts + op.dev_ws; ca.part = e->d_part;
-                if (op.s2q_ok && e->use_s2q && !f16 && src.scale != nullptr) {
-                    // 128-column tiles in split mode: 8-channel chunks, patch and weights double-buffered, conversion inside the MFMA stream (kernels_s2q.h)
-                    ca.wph = wts + op.dev_w2q;
-                    const int gridq = std::min((g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));
-                    TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3s2_q");
-                    static std::atomic<uint64_t> donesq{0};
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_q<0>), donesq));
-                    switch ((e->dbg >> 12) & 15) {
-#define TS2D_SQ(A_) case A_: { static std::atomic<uint64_t> d_{0}; HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_q<A_>), d_)); \
-                            hipLaunchKernelGGL(conv3x3s2_q<A_>, dim3(gridq), dim3(kSqThreads), kSqLds, st, ca); } break;
-                        TS2D_SQ(1) TS2D_SQ(2) TS2D_SQ(4) TS2D_SQ(8) TS2D_SQ(6) TS2D_SQ(14)
-#undef TS2D_SQ
-                        default: hipLaunchKernelGGL(conv3x3s2_q<0>, dim3(gridq), dim3(kSqThreads), kSqLds, st, ca);
-                    }
-                    HIP_TRY(hipGetLastError());
-                    TRY(prof_end(e, st));
-                    TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
-                    launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
-                                       op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
-                    HIP_TRY(hipGetLastError());
-                    TRY(prof_end(e, st));
-                    continue;
-                }
                 const int npp = f16 ? 1 : 2;
                 // persistent: one workgroup per CU walks its tiles; every chunk's weights resident in LDS when they fit beside the patch
                 const size_t wchunk = (size_t)9 * npp * 2 * op.bn2 * 16;
@@ -1342,24 +1306,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const bool h2 = split && f16 && stride == 1 && e->use_h2 && op.cout % 64 == 0 && op.skip < 0 && ct_total(op) % 32 == 0 && g.lgNIMG == 0 && img32 &&
                             Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr && lg_exact(Wt / 32) >= 0 && lg_exact((Wt / 32) * (Ht / 16)) >= 0 &&
                             lg_exact(op.cout / 64) >= 0 && ct_total(op) >= e->h2_min;
-            if (h2 && e->use_hq) {
-                // 16-bit mode, plain C -> C block: the persistent double-buffered pipeline of conv3x3_f16x3_qp on 32-channel chunks (kernels_hq.h)
-                ca.wph = wts + op.dev_wp;
-                ca.tiles_x = Wt / 32; ca.tiles_y = Ht / 16; ca.n_mtiles = B * ca.tiles_x * ca.tiles_y;
-                ca.lg_tx = lg_exact(ca.tiles_x); ca.lg_tpi = lg_exact(ca.tiles_x * ca.tiles_y);
-                const int gridq = (ca.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
-                const int gridp = std::min(gridq, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));     // one persistent workgroup per CU
-                static std::atomic<uint64_t> donehq{0};
-                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_hq<0>), donehq));
-                switch ((e->dbg >> 12) & 15) {
-#define TS2D_HQ(A_) case A_: { static std::atomic<uint64_t> d_{0}; HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_hq<A_>), d_)); \
-                        hipLaunchKernelGGL(conv3x3_hq<A_>, dim3(gridp), dim3(kQThreads), kHqLds, st, ca); } break;
-                    TS2D_HQ(1) TS2D_HQ(2) TS2D_HQ(4) TS2D_HQ(8) TS2D_HQ(6) TS2D_HQ(14)
-#undef TS2D_HQ
-                    default: hipLaunchKernelGGL(conv3x3_hq<0>, dim3(gridp), dim3(kQThreads), kHqLds, st, ca);
-                }
-                le = hipGetLastError(); prof_kernel(e, "conv3x3_hq");
-            } else if (h2) {
+            if (h2) {
                 // 16-bit mode, plain C -> C block on 16 x 32 tiles: the skip phase of conv3x3_upc_h2 (four M tiles per wave, weights by LDS-DMA)
                 UpcArgs ua{};
                 ua.xs = src.data; ua.scs = src.scale; ua.shs = src.shift; ua.Cs = src.C;
@@ -1528,7 +1475,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
     if (!e || !name) return fail(TS2D_ERR_INVALID, "ts2d_engine_set_option: null argument");
     struct B { const char* n; bool* p; };
     struct I { const char* n; int* p; int lo, hi; };
-    const B bools[] = {{"h32", &e->use_h32}, {"one", &e->use_one}, {"s2v2", &e->use_s2v2}, {"q", &e->use_q}, {"h2", &e->use_h2}, {"hq", &e->use_hq}, {"s2q", &e->use_s2q}, {"uh2", &e->use_uh2},
+    const B bools[] = {{"h32", &e->use_h32}, {"one", &e->use_one}, {"s2v2", &e->use_s2v2}, {"q", &e->use_q}, {"h2", &e->use_h2},  {"uh2", &e->use_uh2},
                        {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}};
     const I ints[] = {{"upq_min", &e->upq_min, 0, 1 << 20}, {"h2_min", &e->h2_min, 0, 1 << 20}, {"u0seg", &e->u0seg, 0, 1 << 20}};
     bool found = false;
@@ -1537,7 +1484,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
         if (value < i.lo || value > i.hi) return fail(TS2D_ERR_INVALID, "option %s = %d out of range [%d, %d]", name, value, i.lo, i.hi);
         *i.p = value; found = true;
     }
-    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min hq s2q uh2 up0 u0seg upq upq_min upc res fuse0)", name);
+    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0)", name);
     e->ws_precision = -1;         // which ops compose (and with it the activation plan) depends on the options: re-plan at the next reserve / forward
     return TS2D_OK;
 }
