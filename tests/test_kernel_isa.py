@@ -21,7 +21,9 @@ def asm(tmp_path_factory):
         pytest.skip('hipcc not installed')
     out = tmp_path_factory.mktemp('isa') / 'engine.s'
     src = os.path.join(ROOT, 'totalsegmentator2d_amd', 'csrc', 'engine.hip')
-    subprocess.check_call([HIPCC, '-O3', '-std=c++17', '--offload-arch=gfx950', '--cuda-device-only', '-S', '-o', str(out), src],
+    # (the device-code flags of the shipped build: csrc/Makefile DEVFLAGS)
+    devflags = subprocess.check_output(['make', '-s', '-C', os.path.dirname(src), 'flags'], text=True).split()
+    subprocess.check_call([HIPCC, '-O3', '-std=c++17', '--offload-arch=gfx950', '--cuda-device-only', '-S', *devflags, '-o', str(out), src],
                           stderr=subprocess.DEVNULL)
     return open(out).read()
 

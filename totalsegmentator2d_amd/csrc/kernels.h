@@ -60,6 +60,14 @@ __device__ __forceinline__ void stat_tile_store(const float* red, int nwaves, in
     *reinterpret_cast<f32x4*>(part_entry) = a;
 }
 
+// The library is built WITHOUT packed fp32 VALU instructions (csrc/Makefile: DEVFLAGS); a kernel that is faster with them opts back in.  (A kernel's
+// lambdas and the shared helpers keep the library default: a callee with fewer target features inlines into a caller with more.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TS2D_PACKED_F32 __attribute__((target("packed-fp32-ops")))
+#else
+#define TS2D_PACKED_F32      // (the host pass of hipcc parses the kernels too and does not know the feature)
+#endif
+
 constexpr int kBlock = 256;   // threads per workgroup (4 waves, one per SIMD)
 constexpr int kBM = 256;      // output pixels per workgroup tile
 

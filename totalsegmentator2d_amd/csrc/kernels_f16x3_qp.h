@@ -39,7 +39,7 @@ constexpr int kQThreads = 512, kQRows = 18, kQSlots = kQRows * kPPW, kQPlane = k
 constexpr int kQWts = 9 * 4 * 64 * 16, kQLds = 2 * kQPatch + 2 * kQWts;      // 2 x 39168 (patch) + 2 x 36864 (weights) = 152064 bytes
 constexpr int kQpRed = kQLds, kQpLds = kQLds + 8192;          // + the statistics exchange [8 waves][64 columns] x (S, Q, K, n)
 
-__global__ __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs a) {
+__global__ TS2D_PACKED_F32 __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp(const ConvArgs a) {
     constexpr int BN = 64, NT = 2, MAXU = 5, WTAP = 4 * BN * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     typedef __attribute__((address_space(3))) void* lds_ptr;

@@ -23,7 +23,7 @@ struct FirstArgs {
 // STORE = false (round 4): the statistics-only pass in front of the fused second block (conv3x3_res32<.., FUSE>, kernels_res32.h) - the same
 // values, the same per-tile shifted partials, nothing written but them: the layer's 33.5 MB of output per slice never exist.
 template <int NT, int KP, typename ST = float, bool FULL = false, bool STORE = true>      // NT = Cout / 32 column tiles, KP = ceil(C / 2) channel pairs, ST = output storage
-__global__ __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 1) void conv3x3_first(const FirstArgs a) {
+__global__ TS2D_PACKED_F32 __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 1) void conv3x3_first(const FirstArgs a) {
     constexpr int CP = 2 * KP + 1;               // floats per patch pixel (+1 pad: conflict-free ds_read_b32)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TH = 1 << a.lgTH, TW = 1 << a.lgTW, NIMG = 1 << a.lgNIMG;
