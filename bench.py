@@ -413,7 +413,7 @@ def main():
             layer = {o['name']: (o, m) for o, m in zip(prog, work['per_layer'])}
             ms = {k: v / n_prof for k, v in op_ms.items()}
             # (a) the stride-1 3x3 family of round 1 (22 launches/step, 83 % of the FLOPs), kept for continuity
-            per = {n: 2.0 * m['macs'] for n, (o, m) in layer.items() if o['op'] == OP_CONV3X3 and o['stride'] == 1 and o['src'] != 'input'}
+            per = {n: 2.0 * m['macs'] for n, (o, m) in layer.items() if o['op'] == OP_CONV3X3 and tuple(o['stride']) == (1, 1) and o['src'] != 'input'}
             conv_ms = sum(ms[k] for k in per if k in ms)
             conv_flops = sum(per.values()) * B
             peak = {'split': PEAK_F16_MFMA_TFLOPS / 3.0, 'exact': PEAK_FP32_MFMA_TFLOPS, 'f16': PEAK_F16_MFMA_TFLOPS}[args.precision]

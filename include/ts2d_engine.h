@@ -34,8 +34,10 @@ typedef enum {
 
 /* Architecture descriptor = the `arch_kwargs` of nnU-Net's PlainConvUNet that
  * `nnUNetPredictor.initialize_from_trained_model_folder` (reference call site ts2d/core/inference/nnu.py:165) reads
- * from plans.json.  Supported subset: Conv2d 3x3, stride 1 first stage / 2 afterwards, InstanceNorm2d(affine),
- * LeakyReLU, ConvTranspose2d 2x2 upsampling, 1x1 head.  features[] must be multiples of 32. */
+ * from plans.json.  Supported subset: Conv2d 3x3, stride (1, 1) in the first stage and 1 or 2 PER AXIS afterwards (nnU-Net's
+ * planner pools each axis separately: (2, 2) until one axis is exhausted, then (2, 1) / (1, 2)), InstanceNorm2d(affine), LeakyReLU,
+ * ConvTranspose2d upsampling with kernel = stride = the stride of the stage below, 1x1 head.  features[] must be multiples of 32.
+ * (2, 2) stages run the dedicated kernels; any other stride runs a generic implicit-GEMM kernel (correct, not tuned). */
 typedef struct {
     int32_t input_channels;                 /* C: len(dataset_json['channel_names']) (prediction_worker.py:78) */
     int32_t num_classes;                    /* K: number of segmentation heads (multilabel: one per label) */
@@ -45,6 +47,8 @@ typedef struct {
     int32_t n_conv_dec[TS2D_MAX_STAGES];    /* n_stages-1 entries, bottom-up (decoder.stages.{j}) */
     float norm_eps;                         /* InstanceNorm2d eps (1e-5) */
     float leaky_slope;                      /* LeakyReLU negative_slope (0.01) */
+    int32_t strides[TS2D_MAX_STAGES][2];    /* ABI 7: arch_kwargs['strides'][s] = (along H, along W), 1 or 2 each; [0] = (1, 1).
+                                             * An all-zero entry s >= 1 reads as (2, 2) (descriptors written for ABI <= 6). */
 } ts2d_arch_desc;
 
 /* Arithmetic of the dense 3x3 contractions (storage, accumulation, statistics and I/O are fp32 in both modes):
@@ -104,7 +108,8 @@ int ts2d_engine_weights_ready(ts2d_engine* e);
  *   logits       [B, K, H, W] fp32 NCHW or NULL
  *   mask_packed  [B, K, H, W/32] uint32 or NULL: bit (x & 31) of word x>>5 = (sigmoid(float(logit)) > 0.5), the
  *                multilabel export predicate (reference export_prediction_from_logits, prediction_worker.py:215-221)
- *   H, W         multiples of 2^(n_stages-1); W multiple of 32 when mask_packed != NULL
+ *   H, W         multiples of the product of the strides along their axis (2^(n_stages-1) for an isotropic plan); W multiple of 32
+ *                when mask_packed != NULL
  *   on_device    nonzero: input/logits/mask_packed are device pointers; zero: host pointers (staged by the engine)
  *   stream       hipStream_t as void* (NULL = the engine's own stream).  The call is asynchronous when on_device
  *                != 0 (caller synchronises the stream) and synchronous otherwise. */

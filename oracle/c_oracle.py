@@ -14,7 +14,7 @@ _LIB = None
 class _Arch(ctypes.Structure):
     _fields_ = [('input_channels', ctypes.c_int), ('num_classes', ctypes.c_int), ('n_stages', ctypes.c_int),
                 ('features', ctypes.c_int * 16), ('n_conv_enc', ctypes.c_int * 16), ('n_conv_dec', ctypes.c_int * 16),
-                ('eps', ctypes.c_float), ('slope', ctypes.c_float)]
+                ('eps', ctypes.c_float), ('slope', ctypes.c_float), ('strides', (ctypes.c_int * 2) * 16)]
 
 
 def build():
@@ -47,6 +47,8 @@ def _c_arch(arch) -> _Arch:
     for i, c in enumerate(arch.n_conv_per_stage_decoder):
         a.n_conv_dec[i] = c
     a.eps, a.slope = arch.norm_eps, arch.leaky_slope
+    for i, st in enumerate(arch.strides):
+        a.strides[i][0], a.strides[i][1] = int(st[0]), int(st[1])
     return a
 
 

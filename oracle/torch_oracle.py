@@ -42,7 +42,7 @@ def _h(t):
 
 
 def conv_block(x, w, b, g, be, stride, eps=1e-5, slope=0.01, emulate=None, round_w=True, storage_view=False):
-    """``ConvDropoutNormReLU``: Conv2d(3x3, pad 1, stride) -> InstanceNorm2d(affine, eps, biased var) -> LeakyReLU.
+    """``ConvDropoutNormReLU``: Conv2d(3x3, pad 1, stride = int or (sy, sx)) -> InstanceNorm2d(affine, eps, biased var) -> LeakyReLU.
 
     ``emulate='f16'`` restates the arithmetic CONTRACT of the engine's 16-bit mode (include/ts2d_engine.h, TS2D_PRECISION_F16; to first
     order also the reference's CUDA path, which runs the network under fp16 autocast: ``ts2d/core/inference/nnu.py:159-163``):
@@ -82,17 +82,18 @@ def unet_forward(arch, sd: Dict[str, np.ndarray], x, return_intermediates: bool 
             for i in range(arch.n_conv_per_stage[s]):
                 k = f'encoder.stages.{s}.0.convs.{i}'
                 x = conv_block(x, sd[f'{k}.conv.weight'], sd[f'{k}.conv.bias'], sd[f'{k}.norm.weight'],
-                               sd[f'{k}.norm.bias'], 2 if (i == 0 and s > 0) else 1, arch.norm_eps, arch.leaky_slope,
+                               sd[f'{k}.norm.bias'], tuple(arch.strides[s]) if (i == 0 and s > 0) else 1, arch.norm_eps, arch.leaky_slope,
                                emulate=emulate, round_w=not (s == 0 and i == 0))
                 inter[f'enc{s}.c{i}'] = x
             skips.append(x)
         for j in range(arch.n_stages - 1):
             lvl = arch.n_stages - 2 - j
             k = f'decoder.transpconvs.{j}'
+            st = tuple(arch.strides[lvl + 1])          # upstream UNetDecoder: kernel = stride = the stride of the stage below
             if f16:
-                x = _h(F.conv_transpose2d(x, _h(sd[f'{k}.weight']), sd[f'{k}.bias'], stride=2))
+                x = _h(F.conv_transpose2d(x, _h(sd[f'{k}.weight']), sd[f'{k}.bias'], stride=st))
             else:
-                x = F.conv_transpose2d(x, sd[f'{k}.weight'], sd[f'{k}.bias'], stride=2)
+                x = F.conv_transpose2d(x, sd[f'{k}.weight'], sd[f'{k}.bias'], stride=st)
             inter[f'dec{lvl}.up'] = x
             x = torch.cat((x, skips[lvl]), 1)
             for i in range(arch.n_conv_per_stage_decoder[j]):
@@ -129,7 +130,7 @@ def layer_forward(arch, sd: Dict[str, np.ndarray], name: str, src, skip=None, em
         kind, lvl, i = name[:3], int(name[3:name.index('.')]), int(name[name.index('.c') + 2:])
         if kind == 'enc':
             k = f'encoder.stages.{lvl}.0.convs.{i}'
-            stride = 2 if (i == 0 and lvl > 0) else 1
+            stride = tuple(arch.strides[lvl]) if (i == 0 and lvl > 0) else 1
             rw = not (lvl == 0 and i == 0)
         else:
             j = arch.n_stages - 2 - lvl
@@ -137,7 +138,8 @@ def layer_forward(arch, sd: Dict[str, np.ndarray], name: str, src, skip=None, em
             stride, rw = 1, True
             if i == 0:
                 kt = f'decoder.transpconvs.{j}'
-                up = F.conv_transpose2d(x, _h(sd[f'{kt}.weight']) if f16 else sd[f'{kt}.weight'], sd[f'{kt}.bias'], stride=2)
+                up = F.conv_transpose2d(x, _h(sd[f'{kt}.weight']) if f16 else sd[f'{kt}.weight'], sd[f'{kt}.bias'],
+                                        stride=tuple(arch.strides[lvl + 1]))
                 x = torch.cat((_h(up) if f16 else up, _t(skip).to(torch.float32)), 1)
         return conv_block(x, sd[f'{k}.conv.weight'], sd[f'{k}.conv.bias'], sd[f'{k}.norm.weight'], sd[f'{k}.norm.bias'],
                           stride, arch.norm_eps, arch.leaky_slope, emulate=emulate, round_w=rw, storage_view=storage_view)

@@ -24,12 +24,13 @@ typedef struct {
     int n_conv_enc[16];
     int n_conv_dec[16];
     float eps, slope;
+    int strides[16][2];      /* per stage (sy, sx), 1 or 2 each; stage 0 = (1, 1) */
 } ts2d_ref_arch;
 
-/* K1/K2/K3/K6: Conv2d 3x3, padding 1, stride s, bias.  x [Cin,Hi,Wi] -> y [Cout,Ho,Wo]; w [Cout,Cin,3,3]. */
-static void conv3x3(const float* x, int cin, int hi, int wi, const float* w, const float* b, int cout, int s,
+/* K1/K2/K3/K6: Conv2d 3x3, padding 1, stride (sy, s), bias.  x [Cin,Hi,Wi] -> y [Cout,Ho,Wo]; w [Cout,Cin,3,3]. */
+static void conv3x3(const float* x, int cin, int hi, int wi, const float* w, const float* b, int cout, int sy, int s,
                     float* y, int acc64) {
-    const int ho = hi / s, wo = wi / s;
+    const int ho = hi / sy, wo = wi / s;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int co = 0; co < cout; ++co) {
         double* accd = acc64 ? (double*)malloc(sizeof(double) * ho * wo) : NULL;
@@ -40,7 +41,7 @@ static void conv3x3(const float* x, int cin, int hi, int wi, const float* w, con
             for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) {
                 const float wv = w[(((size_t)co * cin + ci) * 3 + ky) * 3 + kx];
                 for (int oy = 0; oy < ho; ++oy) {
-                    const int iy = oy * s + ky - 1;
+                    const int iy = oy * sy + ky - 1;
                     if (iy < 0 || iy >= hi) continue;
                     /* ox range with 0 <= ox*s + kx - 1 < wi */
                     int ox0 = (kx == 0) ? 1 : 0;
@@ -79,21 +80,21 @@ static void inorm_lrelu(float* y, int c, int hw, const float* g, const float* be
     }
 }
 
-/* K5: ConvTranspose2d k=2 s=2 + bias; w [Cin,Cout,2,2]; x [Cin,Hi,Wi] -> y [Cout,2Hi,2Wi]. */
-static void convT2x2(const float* x, int cin, int hi, int wi, const float* w, const float* b, int cout, float* y,
+/* K5: ConvTranspose2d kernel = stride = (ka, kb) + bias; w [Cin,Cout,ka,kb]; x [Cin,Hi,Wi] -> y [Cout,ka Hi,kb Wi]. */
+static void convT2x2(const float* x, int cin, int hi, int wi, const float* w, const float* b, int cout, int ka, int kb, float* y,
                      int acc64) {
-    const int ho = 2 * hi, wo = 2 * wi;
+    const int ho = ka * hi, wo = kb * wi;
 #pragma omp parallel for
     for (int co = 0; co < cout; ++co) {
         float* out = y + (size_t)co * ho * wo;
-        for (int iy = 0; iy < hi; ++iy) for (int ix = 0; ix < wi; ++ix) for (int a = 0; a < 2; ++a) for (int bb = 0; bb < 2; ++bb) {
+        for (int iy = 0; iy < hi; ++iy) for (int ix = 0; ix < wi; ++ix) for (int a = 0; a < ka; ++a) for (int bb = 0; bb < kb; ++bb) {
             double accd = b[co]; float accf = b[co];
             for (int ci = 0; ci < cin; ++ci) {
                 const float xv = x[((size_t)ci * hi + iy) * wi + ix];
-                const float wv = w[(((size_t)ci * cout + co) * 2 + a) * 2 + bb];
+                const float wv = w[(((size_t)ci * cout + co) * ka + a) * kb + bb];
                 if (acc64) accd += (double)xv * wv; else accf += xv * wv;
             }
-            out[(size_t)(2 * iy + a) * wo + 2 * ix + bb] = acc64 ? (float)accd : accf;
+            out[(size_t)(ka * iy + a) * wo + kb * ix + bb] = acc64 ? (float)accd : accf;
         }
     }
 }
@@ -118,7 +119,15 @@ static void conv1x1(const float* x, int cin, int hw, const float* w, const float
 int ts2d_ref_forward(const ts2d_ref_arch* a, const float* blob, const float* x, int B, int H, int W, float* logits,
                      int acc64) {
     const int n = a->n_stages;
-    if (n < 2 || n > 16 || (H % (1 << (n - 1))) || (W % (1 << (n - 1)))) return 1;
+    if (n < 2 || n > 16) return 1;
+    {
+        int dy = 1, dx = 1;
+        for (int s = 1; s < n; ++s) {
+            if (a->strides[s][0] < 1 || a->strides[s][0] > 2 || a->strides[s][1] < 1 || a->strides[s][1] > 2) return 1;
+            dy *= a->strides[s][0]; dx *= a->strides[s][1];
+        }
+        if (H % dy || W % dx) return 1;
+    }
     float* skip[16];
     for (int b = 0; b < B; ++b) {
         const float* p = blob;
@@ -128,14 +137,14 @@ int ts2d_ref_forward(const ts2d_ref_arch* a, const float* blob, const float* x, 
         for (int s = 0; s < n; ++s) {
             const int f = a->features[s];
             for (int i = 0; i < a->n_conv_enc[s]; ++i) {
-                const int st = (i == 0 && s > 0) ? 2 : 1;
-                const int ho = h / st, wo = w / st;
+                const int sty = (i == 0 && s > 0) ? a->strides[s][0] : 1, stx = (i == 0 && s > 0) ? a->strides[s][1] : 1;
+                const int ho = h / sty, wo = w / stx;
                 float* y = (float*)malloc(sizeof(float) * (size_t)f * ho * wo);
                 const float* wt = p; p += (size_t)f * cin * 9;
                 const float* bi = p; p += f;
                 const float* g = p; p += f;
                 const float* be = p; p += f;
-                conv3x3(cur, cin, h, w, wt, bi, f, st, y, acc64);
+                conv3x3(cur, cin, h, w, wt, bi, f, sty, stx, y, acc64);
                 inorm_lrelu(y, f, ho * wo, g, be, a->eps, a->slope);
                 if (tmp) free(tmp);
                 tmp = y; cur = y; cin = f; h = ho; w = wo;
@@ -144,11 +153,12 @@ int ts2d_ref_forward(const ts2d_ref_arch* a, const float* blob, const float* x, 
         }
         for (int j = 0; j < n - 1; ++j) {
             const int lvl = n - 2 - j, f = a->features[lvl];
-            const float* wt = p; p += (size_t)cin * f * 4;
+            const int ka = a->strides[lvl + 1][0], kb = a->strides[lvl + 1][1];
+            const float* wt = p; p += (size_t)cin * f * ka * kb;
             const float* bi = p; p += f;
-            const int ho = 2 * h, wo = 2 * w;
+            const int ho = ka * h, wo = kb * w;
             float* cat = (float*)malloc(sizeof(float) * (size_t)2 * f * ho * wo);
-            convT2x2(cur, cin, h, w, wt, bi, f, cat, acc64);                                   /* up first ... */
+            convT2x2(cur, cin, h, w, wt, bi, f, ka, kb, cat, acc64);                                   /* up first ... */
             memcpy(cat + (size_t)f * ho * wo, skip[lvl], sizeof(float) * (size_t)f * ho * wo); /* ... then skip */
             if (tmp) free(tmp);
             tmp = cat; cur = cat; cin = 2 * f; h = ho; w = wo;
@@ -158,7 +168,7 @@ int ts2d_ref_forward(const ts2d_ref_arch* a, const float* blob, const float* x, 
                 const float* cb = p; p += f;
                 const float* g = p; p += f;
                 const float* be = p; p += f;
-                conv3x3(cur, cin, h, w, cw, cb, f, 1, y, acc64);
+                conv3x3(cur, cin, h, w, cw, cb, f, 1, 1, y, acc64);
                 inorm_lrelu(y, f, h * w, g, be, a->eps, a->slope);
                 free(tmp);
                 tmp = y; cur = y; cin = f;

@@ -14,10 +14,11 @@ from totalsegmentator2d_amd import prng                      # noqa: E402
 from totalsegmentator2d_amd.arch import UNetArch             # noqa: E402
 
 
-def unet(n_stages, feats, K, cin=2, nconv=2, nconv_dec=None):
+def unet(n_stages, feats, K, cin=2, nconv=2, nconv_dec=None, strides=None):
     nconv_dec = nconv if nconv_dec is None else nconv_dec
+    strides = ((1, 1),) + ((2, 2),) * (n_stages - 1) if strides is None else tuple(tuple(s) for s in strides)
     return UNetArch(input_channels=cin, num_classes=K, n_stages=n_stages, features_per_stage=tuple(feats),
-                    kernel_sizes=((3, 3),) * n_stages, strides=((1, 1),) + ((2, 2),) * (n_stages - 1),
+                    kernel_sizes=((3, 3),) * n_stages, strides=strides,
                     n_conv_per_stage=(nconv,) * n_stages, n_conv_per_stage_decoder=(nconv_dec,) * (n_stages - 1))
 
 
@@ -41,8 +42,12 @@ SMALL_CASES = {
     'xr_1ch': (unet(3, (32, 64, 96), 26, cin=1, nconv=3, nconv_dec=1), 1, 96, 160, 16),
     # features[0] = 64 (head_1x1<64>, BN=64 everywhere), 3 input channels
     'wide64': (unet(3, (64, 64, 128), 7, cin=3), 1, 32, 96, 17),
+    # per-axis strides (nnU-Net pools each axis separately: a plan may end in (2, 1) / (1, 2) stages); the transposed conv's kernel =
+    # stride = the stride of the stage below.  Extents 32x64 -> 16x32 -> 8x16 -> 4x16 / 16x64 -> 16x32 -> 8x16 -> 8x16
+    'aniso_21': (unet(4, (32, 64, 128, 128), 5, strides=((1, 1), (2, 2), (2, 2), (2, 1))), 1, 32, 64, 18),
+    'aniso_12_11': (unet(4, (32, 64, 64, 96), 4, strides=((1, 1), (1, 2), (2, 2), (1, 1))), 1, 16, 64, 19),
 }
-KEEP_INTERMEDIATES = {'k_min2': True, 'k_two3': True}
+KEEP_INTERMEDIATES = {'k_min2': True, 'k_two3': True, 'aniso_21': True, 'aniso_12_11': True}
 
 # name -> (arch, data shape [Z,H,W], patch, step, mirror axes, folds, seed)
 SW_CASES = {

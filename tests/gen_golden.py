@@ -43,8 +43,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'sw':       # only the sliding-window fixtures
         sliding_window_goldens()
         return
+    only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == 'small' else None      # `small NAME ...`: just those small cases
     # (i)+(ii) small architectures: full logits + every intermediate activation (per-kernel parity K1..K7)
     for name, (arch, B, H, W, seed) in cases.SMALL_CASES.items():
+        if only is not None and name not in only:
+            continue
         sd = weights.synthetic_state_dict(arch, seed)
         x = cases.make_input(arch, B, H, W, seed)
         y, inter = O.unet_forward(arch, sd, x, return_intermediates=True)
@@ -54,6 +57,8 @@ def main():
             rec.update({f'inter/{k}': v.numpy() for k, v in inter.items()})
         np.savez_compressed(os.path.join(OUT, f'{name}.npz'), **rec)
         print(name, y.shape, float(np.abs(y).max()))
+    if only is not None:
+        return
     # (iii) canonical net, one 2x512x512 slice: strided samples + checksums + mask hash
     arch = UNetArch.canonical()
     sd = weights.synthetic_state_dict(arch, 1)

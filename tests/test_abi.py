@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_arch_desc_layout_matches_header():
-    assert ctypes.sizeof(_lib.ArchDesc) == 4 * 3 + 4 * 16 * 3 + 4 * 2
+    assert ctypes.sizeof(_lib.ArchDesc) == 4 * 3 + 4 * 16 * 3 + 4 * 2 + 4 * 16 * 2       # ABI 7: + strides[16][2]
+    assert _lib.ArchDesc.strides.offset == 4 * 3 + 4 * 16 * 3 + 4 * 2                      # ... appended: the ABI-6 fields keep their offsets
 
 
 @pytest.mark.skipif(has_gpu(), reason='exercises the no-GPU error path')

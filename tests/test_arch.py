@@ -28,10 +28,31 @@ def test_program_order_and_concat():
     assert ops[-1]['op'] == OP_HEAD1X1 and ops[-1]['key'] == 'decoder.seg_layers.6'
     d = next(o for o in ops if o['name'] == 'dec0.c0')
     assert d['src'] == 'dec0.up' and d['skip'] == 'enc0.c1' and d['cin'] == 32 and d['cin_skip'] == 32   # cat((up, skip), 1)
-    assert next(o for o in ops if o['name'] == 'enc3.c0')['stride'] == 2
+    assert next(o for o in ops if o['name'] == 'enc3.c0')['stride'] == (2, 2)
     keys = [k for k, _ in a.param_specs()]
     assert keys[0] == 'encoder.stages.0.0.convs.0.conv.weight' and 'decoder.transpconvs.0.weight' in keys
     assert dict(a.param_specs())['decoder.transpconvs.0.weight'] == (512, 512, 2, 2)
+
+
+def test_per_axis_strides():
+    """A plan whose last stage pools one axis only (nnU-Net's planner treats the axes separately; e.g. a 640 x 320 patch)."""
+    st = ((1, 1),) + ((2, 2),) * 6 + ((2, 1),)
+    a = UNetArch(strides=st)
+    a.validate()
+    assert a.divisors == (128, 64) and a.divisor == 128
+    assert a.extent(7, 640, 320) == (5, 5) and a.extent(6, 640, 320) == (10, 5) and a.extent(0, 640, 320) == (640, 320)
+    ops = {o['name']: o for o in a.program()}
+    assert ops['enc7.c0']['stride'] == (2, 1) and ops['enc7.c1']['stride'] == (1, 1) and ops['dec6.up']['stride'] == (2, 1)
+    assert ops['dec5.up']['stride'] == (2, 2)
+    assert dict(a.param_specs())['decoder.transpconvs.0.weight'] == (512, 512, 2, 1)      # kernel = stride
+    iso = UNetArch.canonical()
+    # the (2, 1) stage keeps twice the columns at level 7: two 3x3 blocks and a decoder entry cost more, the transposed conv has 2 taps
+    assert a.work(640, 320)['macs'] > iso.work(640, 320)['macs'] * 0.99
+    assert a.n_params() == iso.n_params() - 512 * 512 * 2
+    with pytest.raises(NotImplementedError):
+        UNetArch(strides=((1, 1),) + ((2, 2),) * 6 + ((3, 1),)).validate()
+    with pytest.raises(NotImplementedError):
+        UNetArch(strides=((2, 2),) * 8).validate()
 
 
 def test_validate_rejects_unsupported():
@@ -47,12 +68,13 @@ def test_from_plans():
     plans = {'configurations': {'2d': {'patch_size': [512, 512], 'spacing': [1.5, 1.5], 'architecture': {
         'network_class_name': 'dynamic_network_architectures.architectures.unet.PlainConvUNet',
         'arch_kwargs': {'n_stages': 3, 'features_per_stage': [32, 64, 128], 'conv_op': 'torch.nn.modules.conv.Conv2d',
-                        'kernel_sizes': [[3, 3]] * 3, 'strides': [[1, 1], [2, 2], [2, 2]], 'n_conv_per_stage': [2, 2, 2],
+                        'kernel_sizes': [[3, 3]] * 3, 'strides': [[1, 1], [2, 2], [2, 1]], 'n_conv_per_stage': [2, 2, 2],
                         'n_conv_per_stage_decoder': [2, 2], 'conv_bias': True, 'norm_op': 'torch.nn.modules.instancenorm.InstanceNorm2d',
                         'norm_op_kwargs': {'eps': 1e-05, 'affine': True}, 'dropout_op': None, 'dropout_op_kwargs': None,
                         'nonlin': 'torch.nn.LeakyReLU', 'nonlin_kwargs': {'inplace': True}}}}}}
     a = UNetArch.from_plans(plans, '2d', 2, 18)
     assert a.n_stages == 3 and tuple(a.features_per_stage) == (32, 64, 128) and a.num_classes == 18
+    assert tuple(a.strides[2]) == (2, 1) and a.divisors == (4, 2)
     plans['configurations']['2d']['architecture']['network_class_name'] = 'x.ResidualEncoderUNet'
     with pytest.raises(NotImplementedError):
         UNetArch.from_plans(plans, '2d', 2, 18)

@@ -273,6 +273,52 @@ def test_f16_mode_small_cases(name):
         assert np.abs(lg2 - g).max() <= (2e-3 if name == 'tiny_b37' else TOL)
 
 
+@pytest.mark.parametrize('name', ['aniso_21', 'aniso_12_11'])
+def test_per_axis_strides_in_every_precision_mode(name):
+    """Plans whose stages pool one axis only ((2, 1) / (1, 2) / (1, 1) strides, transposed conv kernel = stride; the reference runs
+    whatever plans.json names: ts2d/core/inference/nnu.py:164-165, prediction_worker.py:76-77).  Such stages run the generic
+    implicit-GEMM kernel in every mode: exact / split against the fp32 goldens at 1e-4, the 16-bit mode against its own oracle per
+    layer (the strided block and the anisotropic transposed conv from the engine's own inputs)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import torch_oracle as O
+    arch, B, H, W, seed = cases.SMALL_CASES[name]
+    sd, blob = blob_for(arch, seed)
+    x = cases.make_input(arch, B, H, W, seed)
+    g = golden(name)
+    prog = {o['name']: o for o in arch.program()}
+    aniso = [n for n, o in prog.items() if tuple(o['stride']) not in ((1, 1), (2, 2)) or (n.endswith('.up') and tuple(o['stride']) != (2, 2))]
+    assert aniso
+    with Engine(arch, blob) as e:
+        e.set_profiling(True)
+        for mode in ('exact', 'split'):
+            e.set_precision(mode)
+            lg, mk = e.forward(x, logits=True, mask=True)
+            assert np.abs(lg - g['logits']).max() <= TOL, mode
+            assert np.array_equal(unpack_mask(mk, W), _oracle_mask(lg))
+            for n in aniso:
+                t = e.debug_tensor(n)
+                assert t.shape == g[f'inter/{n}'].shape and np.abs(t - g[f'inter/{n}']).max() <= TOL, (mode, n)
+            kern = e.op_kernels()
+            assert all(kern[n] in ('conv_mfma_f32', 'convT_mfma_f32') for n in aniso), kern
+        e.set_precision('f16')
+        lg, _ = e.forward(x, logits=True)
+        ref16, inter16 = O.unet_forward(arch, sd, x, return_intermediates=True, emulate='f16')
+        d = lg - ref16.numpy()
+        assert np.abs(d).max() <= F16E_MAX and np.sqrt((d ** 2).mean()) <= F16E_RMS, (float(np.abs(d).max()), float(np.sqrt((d ** 2).mean())))
+        for n in aniso:
+            o = prog[n]
+            got = e.debug_tensor(n)
+            src = e.debug_tensor(o['src'])
+            if n.endswith('.up'):
+                k = o['key']
+                want = O._h(F.conv_transpose2d(O._h(torch.from_numpy(src)), O._h(torch.from_numpy(sd[f'{k}.weight'])), torch.from_numpy(sd[f'{k}.bias']),
+                                               stride=tuple(o['stride']))).numpy()
+            else:
+                want = O.layer_forward(arch, sd, n, src, emulate='f16', storage_view=True).numpy()
+            assert got.shape == want.shape and _f16_layer_ok(n, got, want), (n, float(np.abs(got - want).max()), float(np.sqrt(np.mean((got - want) ** 2))))
+
+
 def test_config3_config5_in_f16():
     """Config 3 (a 26-head sub-model, 512x512) and config 5 (tsxr: 1-channel 1024x1024, 9 stages) in the 16-bit mode, against the
     16-bit oracle (tight) and the fp32 oracle (what the mode costs)."""

@@ -11,7 +11,7 @@ from tests.conftest import golden, blob_for, GOLDEN
 from oracle import c_oracle as C
 from oracle import torch_oracle as O
 
-FAST = ['k_min2', 'k_two3', 'net5_64', 'tiny_b37', 'wide64', 'xr_1ch', 'net5_128']
+FAST = ['k_min2', 'k_two3', 'net5_64', 'tiny_b37', 'wide64', 'xr_1ch', 'net5_128', 'aniso_21', 'aniso_12_11']
 
 
 @pytest.mark.parametrize('name', FAST)
@@ -32,6 +32,51 @@ def test_c_oracle_matches_goldens(name):
     tol = 2e-3 if name == 'tiny_b37' else 1e-4
     assert np.abs(C.unet_forward(arch, blob, x, acc64=False) - g).max() <= tol
     assert np.abs(C.unet_forward(arch, blob, x, acc64=True) - g).max() <= tol
+
+
+def test_anisotropic_strides_follow_plain_torch_modules():
+    """Per-axis strides (nnU-Net pools every axis separately; the plan is whatever the model folder holds: reference
+    ts2d/core/inference/nnu.py:164-165): the oracle's functional restatement equals a network assembled from plain torch.nn modules
+    the way upstream's PlainConvEncoder / UNetDecoder do it - strided first conv of a stage, ConvTranspose2d with kernel = stride =
+    the stride of the stage below, cat((up, skip), 1)."""
+    import torch
+    from torch import nn
+    arch, B, H, W, seed = cases.SMALL_CASES['aniso_21']
+    sd, _ = blob_for(arch, seed)
+    x = torch.from_numpy(cases.make_input(arch, B, H, W, seed))
+
+    def block(cin, cout, stride):
+        return nn.Sequential(nn.Conv2d(cin, cout, 3, stride, 1, bias=True), nn.InstanceNorm2d(cout, eps=arch.norm_eps, affine=True),
+                             nn.LeakyReLU(arch.leaky_slope))
+
+    def load(mod, key):
+        with torch.no_grad():
+            mod[0].weight.copy_(torch.from_numpy(sd[f'{key}.conv.weight'])); mod[0].bias.copy_(torch.from_numpy(sd[f'{key}.conv.bias']))
+            mod[1].weight.copy_(torch.from_numpy(sd[f'{key}.norm.weight'])); mod[1].bias.copy_(torch.from_numpy(sd[f'{key}.norm.bias']))
+    with torch.no_grad():
+        skips, cur, cin = [], x, arch.input_channels
+        for s in range(arch.n_stages):
+            for i in range(arch.n_conv_per_stage[s]):
+                m = block(cin, arch.features_per_stage[s], tuple(arch.strides[s]) if i == 0 else 1)
+                load(m, f'encoder.stages.{s}.0.convs.{i}')
+                cur, cin = m(cur), arch.features_per_stage[s]
+            skips.append(cur)
+        for j in range(arch.n_stages - 1):
+            lvl = arch.n_stages - 2 - j
+            st = tuple(arch.strides[lvl + 1])
+            up = nn.ConvTranspose2d(cin, arch.features_per_stage[lvl], st, st, bias=True)
+            up.weight.copy_(torch.from_numpy(sd[f'decoder.transpconvs.{j}.weight'])); up.bias.copy_(torch.from_numpy(sd[f'decoder.transpconvs.{j}.bias']))
+            cur = torch.cat((up(cur), skips[lvl]), 1)
+            cin = 2 * arch.features_per_stage[lvl]
+            for i in range(arch.n_conv_per_stage_decoder[j]):
+                m = block(cin, arch.features_per_stage[lvl], 1)
+                load(m, f'decoder.stages.{j}.convs.{i}')
+                cur, cin = m(cur), arch.features_per_stage[lvl]
+        k = f'decoder.seg_layers.{arch.n_stages - 2}'
+        y = torch.nn.functional.conv2d(cur, torch.from_numpy(sd[f'{k}.weight']), torch.from_numpy(sd[f'{k}.bias'])).numpy()
+    assert y.shape == (B, arch.num_classes, H, W)
+    assert np.abs(y - golden('aniso_21')['logits']).max() <= 2e-5
+    assert np.abs(y - O.unet_forward(arch, sd, x).numpy()).max() <= 2e-5
 
 
 def test_c_oracle_mask_equals_torch_sigmoid_threshold():

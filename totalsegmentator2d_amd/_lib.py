@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libts2d_engine.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'ts2d_engine.h')
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_STAGES = 16
 PRECISION_F32_EXACT = 0
 PRECISION_F32_SPLIT_F16X3 = 1
@@ -29,7 +29,8 @@ class ArchDesc(ctypes.Structure):
     """``ts2d_arch_desc``."""
     _fields_ = [('input_channels', ctypes.c_int32), ('num_classes', ctypes.c_int32), ('n_stages', ctypes.c_int32),
                 ('features', ctypes.c_int32 * MAX_STAGES), ('n_conv_enc', ctypes.c_int32 * MAX_STAGES),
-                ('n_conv_dec', ctypes.c_int32 * MAX_STAGES), ('norm_eps', ctypes.c_float), ('leaky_slope', ctypes.c_float)]
+                ('n_conv_dec', ctypes.c_int32 * MAX_STAGES), ('norm_eps', ctypes.c_float), ('leaky_slope', ctypes.c_float),
+                ('strides', (ctypes.c_int32 * 2) * MAX_STAGES)]
 
 
 class EngineLibraryError(RuntimeError):

@@ -101,8 +101,10 @@ class UNetArch:
         if tuple(self.strides[0]) != (1, 1):
             raise NotImplementedError("first stage must have stride 1")
         for s in self.strides[1:]:
-            if tuple(s) != (2, 2):
-                raise NotImplementedError(f"stride {tuple(s)} is not supported (2x2 between stages only)")
+            # nnU-Net's planner pools every axis separately (reference: the plan is whatever the model folder holds,
+            # ts2d/core/inference/nnu.py:164-165): (2, 2) until one axis is exhausted, then (2, 1) / (1, 2)
+            if len(s) != 2 or any(int(v) not in (1, 2) for v in s):
+                raise NotImplementedError(f"stride {tuple(s)} is not supported (1 or 2 per axis)")
         if not self.conv_bias or not self.norm_affine:
             raise NotImplementedError("conv_bias=False / affine=False are not supported")
         if self.input_channels < 1 or self.num_classes < 1:
@@ -112,15 +114,35 @@ class UNetArch:
         if any(c < 1 for c in list(self.n_conv_per_stage) + list(self.n_conv_per_stage_decoder)):
             raise ValueError("n_conv_per_stage* must be >= 1")
 
+    def level_shifts(self) -> List[Tuple[int, int]]:
+        """(log2 of the cumulative stride along H, along W) of every stage: a level-s tensor of an H x W input has
+        extent (H >> ly, W >> lx)."""
+        out, ly, lx = [], 0, 0
+        for s in self.strides:
+            ly += int(s[0]) // 2
+            lx += int(s[1]) // 2
+            out.append((ly, lx))
+        return out
+
+    def extent(self, level: int, H: int, W: int) -> Tuple[int, int]:
+        ly, lx = self.level_shifts()[level]
+        return H >> ly, W >> lx
+
+    @property
+    def divisors(self) -> Tuple[int, int]:
+        """H and W must be multiples of these (products of the strides per axis)."""
+        ly, lx = self.level_shifts()[-1]
+        return 2 ** ly, 2 ** lx
+
     @property
     def divisor(self) -> int:
-        """H and W must be multiples of this (product of strides)."""
-        return 2 ** (self.n_stages - 1)
+        """The larger of :attr:`divisors` (both, for an isotropic plan)."""
+        return max(self.divisors)
 
     # ------------------------------------------------------------------ program
     def program(self) -> List[dict]:
         """Flat op list in execution order.  Each entry: op, name, cin (and cin_skip for the virtual concat), cout,
-        stride, level (0 = full resolution), src / skip tensor names, dst name.  ``torch.cat((up, skip), 1)``
+        stride (sy, sx), level (0 = full resolution), src / skip tensor names, dst name.  ``torch.cat((up, skip), 1)``
         (upsampled first - SURVEY K6) is represented by ``cin`` (up) + ``cin_skip`` and never materialised."""
         self.validate()
         ops: List[dict] = []
@@ -128,7 +150,7 @@ class UNetArch:
         for s in range(self.n_stages):
             f = self.features_per_stage[s]
             for i in range(self.n_conv_per_stage[s]):
-                stride = 2 if (i == 0 and s > 0) else 1
+                stride = tuple(int(v) for v in self.strides[s]) if (i == 0 and s > 0) else (1, 1)
                 dst = f'enc{s}.c{i}'
                 ops.append(dict(op=OP_CONV3X3, name=dst, src=cur, skip=None, cin=cin, cin_skip=0, cout=f,
                                 stride=stride, level=s, dst=dst,
@@ -139,23 +161,25 @@ class UNetArch:
             lvl = self.n_stages - 2 - j
             f = self.features_per_stage[lvl]
             up = f'dec{lvl}.up'
-            ops.append(dict(op=OP_CONVT2X2, name=up, src=cur, skip=None, cin=cin, cin_skip=0, cout=f, stride=2,
+            # transposed conv: kernel = stride = the stride of the encoder stage below (upstream UNetDecoder)
+            ops.append(dict(op=OP_CONVT2X2, name=up, src=cur, skip=None, cin=cin, cin_skip=0, cout=f,
+                            stride=tuple(int(v) for v in self.strides[lvl + 1]),
                             level=lvl, dst=up, key=f'decoder.transpconvs.{j}'))
             cur = up
             for i in range(self.n_conv_per_stage_decoder[j]):
                 dst = f'dec{lvl}.c{i}'
                 ops.append(dict(op=OP_CONV3X3, name=dst, src=cur, skip=skips[lvl] if i == 0 else None,
-                                cin=f, cin_skip=f if i == 0 else 0, cout=f, stride=1, level=lvl, dst=dst,
+                                cin=f, cin_skip=f if i == 0 else 0, cout=f, stride=(1, 1), level=lvl, dst=dst,
                                 key=f'decoder.stages.{j}.convs.{i}'))
                 cur = dst
             cin = f
         ops.append(dict(op=OP_HEAD1X1, name='head', src=cur, skip=None, cin=cin, cin_skip=0, cout=self.num_classes,
-                        stride=1, level=0, dst='logits', key=f'decoder.seg_layers.{self.n_stages - 2}'))
+                        stride=(1, 1), level=0, dst='logits', key=f'decoder.seg_layers.{self.n_stages - 2}'))
         return ops
 
     def param_specs(self) -> List[Tuple[str, Tuple[int, ...]]]:
         """(state-dict key, shape) of every tensor of the weight blob, in blob order (PyTorch layouts:
-        conv ``[Cout,Cin,3,3]``, convT ``[Cin,Cout,2,2]``, head ``[K,Cin,1,1]``)."""
+        conv ``[Cout,Cin,3,3]``, convT ``[Cin,Cout,sy,sx]`` (kernel = stride), head ``[K,Cin,1,1]``)."""
         specs: List[Tuple[str, Tuple[int, ...]]] = []
         for op in self.program():
             k, cin, cout = op['key'], op['cin'] + op['cin_skip'], op['cout']
@@ -163,7 +187,7 @@ class UNetArch:
                 specs += [(f'{k}.conv.weight', (cout, cin, 3, 3)), (f'{k}.conv.bias', (cout,)),
                           (f'{k}.norm.weight', (cout,)), (f'{k}.norm.bias', (cout,))]
             elif op['op'] == OP_CONVT2X2:
-                specs += [(f'{k}.weight', (cin, cout, 2, 2)), (f'{k}.bias', (cout,))]
+                specs += [(f'{k}.weight', (cin, cout) + tuple(op['stride'])), (f'{k}.bias', (cout,))]
             else:
                 specs += [(f'{k}.weight', (cout, cin, 1, 1)), (f'{k}.bias', (cout,))]
         return specs
@@ -185,15 +209,16 @@ class UNetArch:
         act = 0
         per_layer = []
         for op in self.program():
-            h, w = H >> op['level'], W >> op['level']
+            h, w = self.extent(op['level'], H, W)
             cin, cout = op['cin'] + op['cin_skip'], op['cout']
+            sy, sx = op['stride']
             if op['op'] == OP_CONV3X3:
                 m = h * w * cout * cin * 9
-                hin, win = h * op['stride'], w * op['stride']
+                hin, win = h * sy, w * sx
                 rd, wr = hin * win * cin * act_bytes, h * w * cout * act_bytes
             elif op['op'] == OP_CONVT2X2:
                 m = h * w * cout * cin          # each output pixel = one tap
-                rd, wr = (h // 2) * (w // 2) * cin * act_bytes, h * w * cout * act_bytes
+                rd, wr = (h // sy) * (w // sx) * cin * act_bytes, h * w * cout * act_bytes
             else:
                 m = h * w * cout * cin
                 rd, wr = h * w * cin * act_bytes, h * w * cout * 4

@@ -56,6 +56,7 @@ enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_HEAD = 2 };
 struct Tensor {            // an activation tensor of the program (NHWC fp32)
     std::string name;
     int C = 0, level = 0;
+    int ly = 0, lx = 0;    // log2 of the cumulative stride along H / W: extent (H >> ly, W >> lx) (per-axis strides, ABI 7)
     bool normed = false;   // raw conv output that carries InstanceNorm scale/shift
     float* data = nullptr; float* scale = nullptr; float* shift = nullptr;
     bool resident = false; // its buffer still holds the values of the last run (no later tensor of the run was placed on it)
@@ -64,7 +65,9 @@ struct Tensor {            // an activation tensor of the program (NHWC fp32)
 struct Op {
     OpType type; std::string name;
     int src, skip, dst;           // tensor indices (skip = -1 if none)
-    int cin, cin_skip, cout, stride, level;
+    int cin, cin_skip, cout, stride, level;      // stride: 1 = (1, 1), 2 = (2, 2) - the dedicated kernels; 3 = anisotropic (generic kernel only)
+    int sy = 1, sx = 1;           // stride along H / W (conv: of the conv; transposed conv: kernel = stride of the upsampling)
+    int ly = 0, lx = 0;           // shifts of the op's level (= of its output tensor; the head: level 0)
     int ck;                       // Cin chunk of the packed weight layout
     size_t blob_w, blob_b, blob_g, blob_be;     // offsets (floats) into the PyTorch-layout blob
     size_t dev_w, dev_b, dev_g, dev_be;         // offsets (floats) into the device weight arena
@@ -117,6 +120,7 @@ inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 struct ts2d_engine {
     ts2d_arch_desc arch{};
+    int lvl_y[TS2D_MAX_STAGES] = {0}, lvl_x[TS2D_MAX_STAGES] = {0};      // per stage: log2 of the cumulative stride along H / W
     int device = 0;
     int cin_pad = 8;
     std::vector<Tensor> tensors;
@@ -177,7 +181,7 @@ int tensor_index(ts2d_engine* e, const std::string& name) {
 }
 
 int add_tensor(ts2d_engine* e, const std::string& name, int C, int level, bool normed) {
-    Tensor t; t.name = name; t.C = C; t.level = level; t.normed = normed;
+    Tensor t; t.name = name; t.C = C; t.level = level; t.normed = normed; t.ly = e->lvl_y[level]; t.lx = e->lvl_x[level];
     e->tensors.push_back(t);
     return (int)e->tensors.size() - 1;
 }
@@ -194,6 +198,17 @@ int build_program(ts2d_engine* e) {
         if (s < a.n_stages - 1 && a.n_conv_dec[s] < 1) return fail(TS2D_ERR_INVALID, "n_conv_dec[%d] must be >= 1", s);
     }
     if (a.features[0] != 32 && a.features[0] != 64) return fail(TS2D_ERR_INVALID, "features[0] = %d: the head kernel supports 32 or 64", a.features[0]);
+    // per-axis strides (ABI 7).  An all-zero entry = (2, 2): descriptors written for ABI <= 6 carry no strides.
+    int st[TS2D_MAX_STAGES][2];
+    for (int s = 0; s < a.n_stages; ++s) {
+        st[s][0] = a.strides[s][0]; st[s][1] = a.strides[s][1];
+        if (st[s][0] == 0 && st[s][1] == 0) { st[s][0] = st[s][1] = (s == 0) ? 1 : 2; }
+        if (st[s][0] < 1 || st[s][0] > 2 || st[s][1] < 1 || st[s][1] > 2)
+            return fail(TS2D_ERR_INVALID, "strides[%d] = (%d, %d): 1 or 2 per axis", s, st[s][0], st[s][1]);
+        if (s == 0 && (st[0][0] != 1 || st[0][1] != 1)) return fail(TS2D_ERR_INVALID, "strides[0] must be (1, 1)");
+        e->lvl_y[s] = (s ? e->lvl_y[s - 1] : 0) + (st[s][0] == 2); e->lvl_x[s] = (s ? e->lvl_x[s - 1] : 0) + (st[s][1] == 2);
+    }
+    auto stride_code = [](int sy, int sx) { return sy == 1 && sx == 1 ? 1 : (sy == 2 && sx == 2 ? 2 : 3); };
     e->cin_pad = (a.input_channels + 7) / 8 * 8;
     size_t bo = 0;
     int cur = add_tensor(e, "input", e->cin_pad, 0, false), cin = a.input_channels;
@@ -204,7 +219,9 @@ int build_program(ts2d_engine* e) {
         for (int i = 0; i < a.n_conv_enc[s]; ++i) {
             snprintf(nm, sizeof(nm), "enc%d.c%d", s, i);
             Op op{}; op.type = OP_CONV; op.name = nm; op.src = cur; op.skip = -1;
-            op.cin = cin; op.cin_skip = 0; op.cout = f; op.stride = (i == 0 && s > 0) ? 2 : 1; op.level = s;
+            op.cin = cin; op.cin_skip = 0; op.cout = f; op.level = s; op.ly = e->lvl_y[s]; op.lx = e->lvl_x[s];
+            if (i == 0 && s > 0) { op.sy = st[s][0]; op.sx = st[s][1]; }
+            op.stride = stride_code(op.sy, op.sx);
             op.dst = add_tensor(e, nm, f, s, true);
             op.blob_w = bo; bo += (size_t)f * cin * 9; op.blob_b = bo; bo += f; op.blob_g = bo; bo += f; op.blob_be = bo; bo += f;
             e->ops.push_back(op);
@@ -216,14 +233,16 @@ int build_program(ts2d_engine* e) {
         const int lvl = a.n_stages - 2 - j, f = a.features[lvl];
         snprintf(nm, sizeof(nm), "dec%d.up", lvl);
         Op up{}; up.type = OP_CONVT; up.name = nm; up.src = cur; up.skip = -1; up.cin = cin; up.cin_skip = 0; up.cout = f;
-        up.stride = 2; up.level = lvl; up.dst = add_tensor(e, nm, f, lvl, false);
-        up.blob_w = bo; bo += (size_t)cin * f * 4; up.blob_b = bo; bo += f;
+        up.sy = st[lvl + 1][0]; up.sx = st[lvl + 1][1];       // kernel = stride = the stride of the encoder stage below (upstream UNetDecoder)
+        up.stride = stride_code(up.sy, up.sx); up.level = lvl; up.ly = e->lvl_y[lvl]; up.lx = e->lvl_x[lvl];
+        up.dst = add_tensor(e, nm, f, lvl, false);
+        up.blob_w = bo; bo += (size_t)cin * f * up.sy * up.sx; up.blob_b = bo; bo += f;
         e->ops.push_back(up);
         cur = up.dst;
         for (int i = 0; i < a.n_conv_dec[j]; ++i) {
             snprintf(nm, sizeof(nm), "dec%d.c%d", lvl, i);
             Op op{}; op.type = OP_CONV; op.name = nm; op.src = cur; op.skip = (i == 0) ? skips[lvl] : -1;
-            op.cin = f; op.cin_skip = (i == 0) ? f : 0; op.cout = f; op.stride = 1; op.level = lvl;
+            op.cin = f; op.cin_skip = (i == 0) ? f : 0; op.cout = f; op.stride = 1; op.level = lvl; op.ly = e->lvl_y[lvl]; op.lx = e->lvl_x[lvl];
             op.dst = add_tensor(e, nm, f, lvl, true);
             const int ct = op.cin + op.cin_skip;
             op.blob_w = bo; bo += (size_t)f * ct * 9; op.blob_b = bo; bo += f; op.blob_g = bo; bo += f; op.blob_be = bo; bo += f;
@@ -245,11 +264,11 @@ int build_program(ts2d_engine* e) {
         const int ct = op.cin + op.cin_skip;
         if (op.type == OP_CONV) {
             const int ctp = (op.src == 0) ? e->cin_pad : ct;             // first conv reads the zero-padded input
-            op.ck = (op.stride == 2 || ctp % 16) ? 8 : 16;
+            op.ck = (op.stride != 1 || ctp % 16) ? 8 : 16;
             op.dev_w_floats = (size_t)ctp * 9 * op.cout;
         } else if (op.type == OP_CONVT) {
             op.ck = 16;
-            op.dev_w_floats = (size_t)ct * 4 * op.cout;
+            op.dev_w_floats = (size_t)ct * op.sy * op.sx * op.cout;
         } else {
             op.ck = 0;
             op.dev_w_floats = (size_t)ct * op.cout;
@@ -273,7 +292,7 @@ int build_program(ts2d_engine* e) {
             }
             const size_t oi = (size_t)(&op - e->ops.data());
             if (op.stride == 1 && op.skip >= 0 && oi > 0 && e->ops[oi - 1].type == OP_CONVT && e->ops[oi - 1].dst == op.src &&
-                e->ops[oi - 1].cin % 32 == 0 && op.cin % 16 == 0 && op.cin_skip % 16 == 0 && op.cout % 32 == 0 &&
+                e->ops[oi - 1].stride == 2 && e->ops[oi - 1].cin % 32 == 0 && op.cin % 16 == 0 && op.cin_skip % 16 == 0 && op.cout % 32 == 0 &&
                 (double)op.cout * e->ops[oi - 1].cin * op.cin * 36.0 <= 6.0e9) {        // (host composition cost bound: 512 x 512 x 512 channels = 4.8 GFLOP, about a second)
                 const int cb = e->ops[oi - 1].cin;
                 op.upc_ok = true; op.up_idx = (int)oi - 1;
@@ -301,7 +320,7 @@ int build_program(ts2d_engine* e) {
             op.dev_wh = wo; wo = align_up(wo + 2 * 32 * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);
         }
-        if (op.type == OP_CONVT && ct % 32 == 0) {                      // [chunk32][column tile of 64][k-step 2][column][32 halves]
+        if (op.type == OP_CONVT && op.stride == 2 && ct % 32 == 0) {    // [chunk32][column tile of 64][k-step 2][column][32 halves]
             op.split_ok = true;
             op.dev_wh = wo; wo = align_up(wo + (size_t)(ct / 32) * 2 * 4 * op.cout * 16, 64);
             op.dev_ws = wo; wo = align_up(wo + 1, 64);
@@ -559,15 +578,15 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
             });
             memcpy(out + op.dev_g, blob + op.blob_g, co_n * sizeof(float));
             memcpy(out + op.dev_be, blob + op.blob_be, co_n * sizeof(float));
-        } else if (op.type == OP_CONVT) {   // W[ci][co][a][b] -> [chunk][kk][(a*2+b)*Cout + co][8]
-            const int ck = op.ck, kkn = ck / 8, N = 4 * co_n;
+        } else if (op.type == OP_CONVT) {   // W[ci][co][a][b] -> [chunk][kk][(a*KB+b)*Cout + co][8]   (kernel = stride = (KA, KB))
+            const int ck = op.ck, kkn = ck / 8, nab = op.sy * op.sx, N = nab * co_n;
             const float* w = blob + op.blob_w;
             float* d = out + op.dev_w;
             for (int ci = 0; ci < ct; ++ci) {
                 const int chunk = ci / ck, cc = ci % ck, kk = cc / 8, el = cc % 8;
                 for (int co = 0; co < co_n; ++co)
-                    for (int ab = 0; ab < 4; ++ab)
-                        d[(((size_t)chunk * kkn + kk) * N + ab * co_n + co) * 8 + el] = w[((size_t)ci * co_n + co) * 4 + ab];
+                    for (int ab = 0; ab < nab; ++ab)
+                        d[(((size_t)chunk * kkn + kk) * N + ab * co_n + co) * 8 + el] = w[((size_t)ci * co_n + co) * nab + ab];
             }
         } else {                            // head W[k][c] as is
             memcpy(out + op.dev_w, blob + op.blob_w, (size_t)ct * co_n * sizeof(float));
@@ -593,7 +612,7 @@ inline int ct_total(const Op& op) { return op.cin + op.cin_skip; }
 
 struct TileGeom { int lgTH, lgTW, lgNIMG, tiles_x, tiles_y, n_mtiles, PH, PW; };
 
-TileGeom tile_geom(int B, int Ht, int Wt, int stride, int taps) {
+TileGeom tile_geom(int B, int Ht, int Wt, int sy, int sx, int taps) {
     TileGeom g{};
     const int TW = std::min(32, pow2ceil(Wt));
     const int TH = std::min(pow2ceil(Ht), kBM / TW);
@@ -606,28 +625,42 @@ TileGeom tile_geom(int B, int Ht, int Wt, int stride, int taps) {
     const int groups = (B + NIMG - 1) / NIMG;
     g.n_mtiles = groups * g.tiles_x * g.tiles_y;
     const int halo = (taps == 9) ? 3 : 1;
-    g.PH = (TH - 1) * stride + halo; g.PW = (TW - 1) * stride + halo;
+    g.PH = (TH - 1) * sy + halo; g.PW = (TW - 1) * sx + halo;
     return g;
 }
 
-template <int TAPS, int STRIDE, int CK, int BN, int EPI>
+template <int TAPS, int SY, int SX, int CK, int BN, int EPI, typename ST = float>
 hipError_t launch_conv_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
     static std::atomic<uint64_t> attr_done{0};
-    auto kern = conv_mfma_f32<TAPS, STRIDE, CK, BN, EPI>;
+    auto kern = conv_mfma_f32<TAPS, SY, SX, CK, BN, EPI, ST>;
     if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(kern), attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), smem, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_conv(int taps, int stride, int ck, int bn, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
-    if (taps == 9 && stride == 1 && ck == 16 && bn == 32) return launch_conv_inst<9, 1, 16, 32, 0>(a, grid, smem, st);
-    if (taps == 9 && stride == 1 && ck == 16 && bn == 64) return launch_conv_inst<9, 1, 16, 64, 0>(a, grid, smem, st);
-    if (taps == 9 && stride == 1 && ck == 8 && bn == 32) return launch_conv_inst<9, 1, 8, 32, 0>(a, grid, smem, st);
-    if (taps == 9 && stride == 1 && ck == 8 && bn == 64) return launch_conv_inst<9, 1, 8, 64, 0>(a, grid, smem, st);
-    if (taps == 9 && stride == 2 && ck == 8 && bn == 32) return launch_conv_inst<9, 2, 8, 32, 0>(a, grid, smem, st);
-    if (taps == 9 && stride == 2 && ck == 8 && bn == 64) return launch_conv_inst<9, 2, 8, 64, 0>(a, grid, smem, st);
-    if (taps == 1 && stride == 1 && ck == 16 && bn == 32) return launch_conv_inst<1, 1, 16, 32, 1>(a, grid, smem, st);
-    if (taps == 1 && stride == 1 && ck == 16 && bn == 64) return launch_conv_inst<1, 1, 16, 64, 1>(a, grid, smem, st);
+// The generic implicit-GEMM kernel: the whole exact mode (fp32 storage), and - in every mode - the stages whose stride is neither
+// (1, 1) nor (2, 2) (f16 = fp16 storage with the 16-bit mode's operand rounding).
+hipError_t launch_conv(int taps, int sy, int sx, int ck, int bn, bool f16, const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
+    const bool b64 = bn == 64;
+    if (bn != 32 && bn != 64) return hipErrorInvalidConfiguration;
+    if (taps == 9 && sy == 1 && sx == 1 && !f16) {
+        if (ck == 16) return b64 ? launch_conv_inst<9, 1, 1, 16, 64, 0>(a, grid, smem, st) : launch_conv_inst<9, 1, 1, 16, 32, 0>(a, grid, smem, st);
+        if (ck == 8) return b64 ? launch_conv_inst<9, 1, 1, 8, 64, 0>(a, grid, smem, st) : launch_conv_inst<9, 1, 1, 8, 32, 0>(a, grid, smem, st);
+    }
+    if (taps == 9 && sy == 2 && sx == 2 && ck == 8 && !f16)
+        return b64 ? launch_conv_inst<9, 2, 2, 8, 64, 0>(a, grid, smem, st) : launch_conv_inst<9, 2, 2, 8, 32, 0>(a, grid, smem, st);
+    if (taps == 9 && sy == 2 && sx == 1 && ck == 8) {
+        if (f16) return b64 ? launch_conv_inst<9, 2, 1, 8, 64, 0, _Float16>(a, grid, smem, st) : launch_conv_inst<9, 2, 1, 8, 32, 0, _Float16>(a, grid, smem, st);
+        return b64 ? launch_conv_inst<9, 2, 1, 8, 64, 0>(a, grid, smem, st) : launch_conv_inst<9, 2, 1, 8, 32, 0>(a, grid, smem, st);
+    }
+    if (taps == 9 && sy == 1 && sx == 2 && ck == 8) {
+        if (f16) return b64 ? launch_conv_inst<9, 1, 2, 8, 64, 0, _Float16>(a, grid, smem, st) : launch_conv_inst<9, 1, 2, 8, 32, 0, _Float16>(a, grid, smem, st);
+        return b64 ? launch_conv_inst<9, 1, 2, 8, 64, 0>(a, grid, smem, st) : launch_conv_inst<9, 1, 2, 8, 32, 0>(a, grid, smem, st);
+    }
+    if (taps == 1 && ck == 16) {      // transposed conv, kernel = stride = (a.KA, a.KB)
+        if (f16) return b64 ? launch_conv_inst<1, 1, 1, 16, 64, 1, _Float16>(a, grid, smem, st) : launch_conv_inst<1, 1, 1, 16, 32, 1, _Float16>(a, grid, smem, st);
+        return b64 ? launch_conv_inst<1, 1, 1, 16, 64, 1>(a, grid, smem, st) : launch_conv_inst<1, 1, 1, 16, 32, 1>(a, grid, smem, st);
+    }
     return hipErrorInvalidConfiguration;
 }
 
@@ -731,7 +764,7 @@ void launch_stats_direct(bool f16, int B, int C, int HW, const float* x, const f
 // Split-K factor for a split-fp16 conv whose grid would leave most CUs idle (8x8 / 4x4 bottleneck levels).
 int choose_ksplit(const ts2d_engine* e, const Op& op, int B, int H, int W) {
     if (op.type != OP_CONV || !op.split_ok || op.first_direct) return 1;
-    const TileGeom g = tile_geom(B, H >> op.level, W >> op.level, op.stride, 9);
+    const TileGeom g = tile_geom(B, H >> op.ly, W >> op.lx, op.sy, op.sx, 9);
     // The factor depends on the layer geometry only (never on B), so a slice computes bit-identically alone or in a batch:
     // tiles that hold >= 4 whole images (<= 8x8 pixels per image) leave most CUs idle -> split K as far as 4 chunks/slice.
     (void)B;
@@ -746,7 +779,7 @@ size_t partial_floats_needed(const ts2d_engine* e, int B, int H, int W) {
     size_t mx = 0;
     for (const Op& op : e->ops) {
         const int S = choose_ksplit(e, op, B, H, W);
-        if (S > 1) mx = std::max(mx, (size_t)S * B * (H >> op.level) * (W >> op.level) * op.cout);
+        if (S > 1) mx = std::max(mx, (size_t)S * B * (H >> op.ly) * (W >> op.lx) * op.cout);
     }
     return mx;
 }
@@ -755,8 +788,8 @@ size_t part_floats_needed(const ts2d_engine* e, int B, int H, int W) {
     size_t mx = 0;
     for (const Op& op : e->ops) {
         if (op.type != OP_CONV) continue;
-        const int Ht = H >> op.level, Wt = W >> op.level;
-        TileGeom g = tile_geom(B, Ht, Wt, op.stride, 9);
+        const int Ht = H >> op.ly, Wt = W >> op.lx;
+        TileGeom g = tile_geom(B, Ht, Wt, op.sy, op.sx, 9);
         if (g.lgNIMG == 0) mx = std::max(mx, (size_t)B * g.tiles_x * g.tiles_y * op.cout * 4);      // (S, Q, K, n) per (tile, channel)
     }
     return mx;
@@ -775,7 +808,7 @@ struct ActPlan { std::vector<size_t> off; std::vector<char> used, reused; size_t
 ActPlan plan_activations(const ts2d_engine* e, int B, int H, int W, bool keep) {
     const size_t nt = e->tensors.size(), no = e->ops.size();
     ActPlan p; p.off.assign(nt, 0); p.used.assign(nt, 0); p.reused.assign(nt, 0);
-    auto bytes_of = [&](size_t t) { const Tensor& x = e->tensors[t]; return align_up((size_t)B * (H >> x.level) * (W >> x.level) * x.C * sizeof(float), 256); };
+    auto bytes_of = [&](size_t t) { const Tensor& x = e->tensors[t]; return align_up((size_t)B * (H >> x.ly) * (W >> x.lx) * x.C * sizeof(float), 256); };
     // which ops run, what they read
     std::vector<char> skipped(no, 0);
     std::vector<std::vector<int>> reads(no);
@@ -987,7 +1020,7 @@ bool upc_applies(const ts2d_engine* e, const Op& op, int B, int H, int W) {
     if (!op.upc_ok || !e->use_upc || !e->use_one || e->precision == TS2D_PRECISION_F32_EXACT) return false;
     if (e->precision == TS2D_PRECISION_F16 && (op.cin_skip % 32 || !e->tensors[e->ops[op.up_idx].src].normed || !e->tensors[op.skip].normed))
         return false;                       // (the 16-bit kernel walks the skip channels in chunks of 32 and normalises both sources)
-    const int Ht = H >> op.level, Wt = W >> op.level;
+    const int Ht = H >> op.ly, Wt = W >> op.lx;
     if (Ht % 8 || Wt % 32) return false;
     if (up0_applies(e, op, Ht, Wt)) return B > 0;       // (walks its tiles by division: any tile count)
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
@@ -1022,7 +1055,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
         const float* wts = e->d_weights;
         if (op.first_direct) {
             Tensor& dst = e->tensors[op.dst];
-            const TileGeom g = tile_geom(B, H, W, 1, 9);
+            const TileGeom g = tile_geom(B, H, W, 1, 1, 9);
             FirstArgs fa{};
             fa.x = d_in; fa.w = wts + op.dev_wraw; fa.bias = wts + op.dev_b; fa.dst = dst.data;
             const bool fused = g.lgNIMG == 0;
@@ -1076,7 +1109,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
         if (op.type == OP_CONV && op.up_idx >= 0 && e->fused_away[op.up_idx]) {
             const Op& up = e->ops[op.up_idx];
             const Tensor& xc = e->tensors[up.src]; const Tensor& sk = e->tensors[op.skip]; Tensor& dst = e->tensors[op.dst];
-            const int Ht = H >> op.level, Wt = W >> op.level, bn = op.cout % 64 == 0 ? 64 : 32;
+            const int Ht = H >> op.ly, Wt = W >> op.lx, bn = op.cout % 64 == 0 ? 64 : 32;
             UpcArgs ua{};
             ua.xc = xc.data; ua.scc = xc.scale; ua.shc = xc.shift; ua.Cb = up.cin;
             ua.xs = sk.data; ua.scs = sk.scale; ua.shs = sk.shift; ua.Cs = op.cin_skip;
@@ -1171,10 +1204,12 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
         if (op.type == OP_CONV || op.type == OP_CONVT) {
             const bool conv = op.type == OP_CONV;
             Tensor& dst = e->tensors[op.dst];
-            const int Hin = H >> src.level, Win = W >> src.level;
-            const int Ht = conv ? (H >> op.level) : Hin, Wt = conv ? (W >> op.level) : Win;
-            const int taps = conv ? 9 : 1, stride = conv ? op.stride : 1;
-            const TileGeom g = tile_geom(B, Ht, Wt, stride, taps);
+            const int Hin = H >> src.ly, Win = W >> src.lx;
+            const int Ht = conv ? (H >> op.ly) : Hin, Wt = conv ? (W >> op.lx) : Win;
+            const int taps = conv ? 9 : 1, stride = conv ? op.stride : 1;      // (the transposed conv tiles its INPUT pixels)
+            const bool aniso = conv ? op.stride == 3 : op.stride != 2;          // conv stride other than (1, 1) / (2, 2), transposed conv other than 2 x 2:
+                                                                                // the generic kernel, in every mode
+            const TileGeom g = tile_geom(B, Ht, Wt, conv ? op.sy : 1, conv ? op.sx : 1, taps);
             ConvArgs ca{};
             ca.ksplit = 1; ca.dbg = e->dbg;
             ca.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
@@ -1184,7 +1219,8 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const bool fused = conv && g.lgNIMG == 0;
             ca.part = fused ? e->d_part : nullptr;
             ca.B = B; ca.Hin = Hin; ca.Win = Win; ca.Ht = Ht; ca.Wt = Wt;
-            ca.N = conv ? op.cout : 4 * op.cout; ca.Cout = op.cout;
+            ca.KA = conv ? 1 : op.sy; ca.KB = conv ? 1 : op.sx;
+            ca.N = conv ? op.cout : op.sy * op.sx * op.cout; ca.Cout = op.cout;
             ca.lgTH = g.lgTH; ca.lgTW = g.lgTW; ca.lgNIMG = g.lgNIMG; ca.tiles_x = g.tiles_x; ca.tiles_y = g.tiles_y;
             const int bn = (ca.N % 64 == 0 && op.cout % 64 == 0) ? 64 : 32;
             ca.n_mtiles = g.n_mtiles; ca.n_ctiles = ca.N / bn; ca.PH = g.PH; ca.PW = g.PW; ca.slope = a.leaky_slope;
@@ -1192,7 +1228,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             ca.lg_tx = lg_exact(g.tiles_x); ca.lg_tpi = lg_exact(g.tiles_x * g.tiles_y); ca.lg_nct = lg_exact(ca.n_ctiles);
             const int P = (g.PH * g.PW) << g.lgNIMG;
             const bool split = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT;
-            if (f16 && !split) return fail(TS2D_ERR_INVALID, "op %s has no fp16 kernel (channel counts must be multiples of 16)", op.name.c_str());
+            if (f16 && !split && !aniso) return fail(TS2D_ERR_INVALID, "op %s has no fp16 kernel (channel counts must be multiples of 16)", op.name.c_str());
             if (conv && split && op.s2v2_ok && e->use_s2v2 && e->use_one && stride == 2 && g.lgNIMG == 0 && Ht % 8 == 0 && Wt % 32 == 0 &&
                 ca.lg_tx >= 0 && ca.lg_tpi >= 0 && lg_exact(op.cout / op.bn2) >= 0 &&
                 (size_t)Hin * Win * op.cin * 4 < ((size_t)1 << 31) && (size_t)Ht * Wt * op.cout * 4 < ((size_t)1 << 31)) {
@@ -1345,7 +1381,8 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                                  : launch_split_s2(f16, bn, P <= 5 * kBlock ? 5 : 6, ca, grid, smem, st);
                 prof_kernel(e, stride == 1 ? "conv3x3_f16x3" : "conv3x3s2_f16x3");
             } else {
-                le = launch_conv(taps, stride, op.ck, bn, ca, grid, smem, st); prof_kernel(e, conv ? "conv_mfma_f32" : "convT_mfma_f32");
+                le = launch_conv(taps, conv ? op.sy : 1, conv ? op.sx : 1, op.ck, bn, f16 && aniso, ca, grid, smem, st);
+                prof_kernel(e, conv ? "conv_mfma_f32" : "convT_mfma_f32");
             }
             if (le != hipSuccess) return fail(TS2D_ERR_HIP, "launch of %s failed: %s", op.name.c_str(), hipGetErrorString(le));
             TRY(prof_end(e, st));
@@ -1408,7 +1445,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
 // ------------------------------------------------------------------------------------------------- C-ABI
 extern "C" {
 
-int ts2d_abi_version(void) { return 6; }
+int ts2d_abi_version(void) { return 7; }
 
 const char* ts2d_last_error(void) { return g_err.c_str(); }
 
@@ -1510,10 +1547,10 @@ int ts2d_engine_weights_ready(ts2d_engine* e) {
 
 int ts2d_engine_reserve(ts2d_engine* e, int B, int H, int W) {
     if (!e) return fail(TS2D_ERR_INVALID, "ts2d_engine_reserve: null engine");
-    const int div = 1 << (e->arch.n_stages - 1);
-    if (B < 1 || H < div || W < div || H % div || W % div)
-        return fail(TS2D_ERR_INVALID, "shape B=%d H=%d W=%d: H and W must be positive multiples of %d", B, H, W, div);
-    if ((H / div) * (W / div) <= 1)   // torch InstanceNorm2d raises "Expected more than 1 spatial element" here too
+    const int divy = 1 << e->lvl_y[e->arch.n_stages - 1], divx = 1 << e->lvl_x[e->arch.n_stages - 1];
+    if (B < 1 || H < divy || W < divx || H % divy || W % divx)
+        return fail(TS2D_ERR_INVALID, "shape B=%d H=%d W=%d: H and W must be positive multiples of %d and %d", B, H, W, divy, divx);
+    if ((H / divy) * (W / divx) <= 1)   // torch InstanceNorm2d raises "Expected more than 1 spatial element" here too
         return fail(TS2D_ERR_INVALID, "shape %dx%d leaves a single bottleneck pixel: InstanceNorm needs more than 1 spatial element", H, W);
     if ((long long)B * H * W >= (1LL << 31)) return fail(TS2D_ERR_INVALID, "B*H*W = %lld exceeds 2^31 pixels per call", (long long)B * H * W);
     return ensure_workspace(e, B, H, W);
@@ -1521,9 +1558,9 @@ int ts2d_engine_reserve(ts2d_engine* e, int B, int H, int W) {
 
 int ts2d_engine_workspace_bytes(ts2d_engine* e, int B, int H, int W, size_t* n_bytes) {
     if (!e || !n_bytes) return fail(TS2D_ERR_INVALID, "ts2d_engine_workspace_bytes: null argument");
-    const int div = 1 << (e->arch.n_stages - 1);
-    if (B < 1 || H < div || W < div || H % div || W % div)
-        return fail(TS2D_ERR_INVALID, "shape B=%d H=%d W=%d: H and W must be positive multiples of %d", B, H, W, div);
+    const int divy = 1 << e->lvl_y[e->arch.n_stages - 1], divx = 1 << e->lvl_x[e->arch.n_stages - 1];
+    if (B < 1 || H < divy || W < divx || H % divy || W % divx)
+        return fail(TS2D_ERR_INVALID, "shape B=%d H=%d W=%d: H and W must be positive multiples of %d and %d", B, H, W, divy, divx);
     *n_bytes = workspace_layout(e, B, H, W).bytes;
     return TS2D_OK;
 }
@@ -1678,7 +1715,7 @@ int ts2d_engine_check(ts2d_engine* e) {
             if (oi < e->fused_away.size() && e->fused_away[oi]) continue;        // not materialised in the last run
             const Tensor& t = e->tensors[op.dst];
             if (!t.resident || !t.data) continue;                              // overwritten by a later activation of the run
-            const size_t n = (size_t)B * (H >> t.level) * (W >> t.level) * t.C;
+            const size_t n = (size_t)B * (H >> t.ly) * (W >> t.lx) * t.C;
             const int f = has_nonfinite(t.data, n, e->last_f16);
             const int g = (f == 0 && t.normed) ? has_nonfinite(t.scale, (size_t)B * t.C, false) : 0;
             if (f == 1 || g == 1) { where = "layer " + op.name + (f == 1 ? "" : " (InstanceNorm statistics)"); named = true; break; }
@@ -1851,7 +1888,7 @@ int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_
         if (e->fused_away[oi] && e->ops[oi].dst == ti)
             return fail(TS2D_ERR_INVALID, "tensor '%s' was not materialised by the last run: the transposed conv is composed into the next block "
                         "(ts2d_engine_set_option(e, \"upc\", 0) runs it as its own kernel)", name);
-    const int B = e->lastB, h = e->lastH >> t.level, w = e->lastW >> t.level, C = t.C;
+    const int B = e->lastB, h = e->lastH >> t.ly, w = e->lastW >> t.lx, C = t.C;
     dims[0] = B; dims[1] = C; dims[2] = h; dims[3] = w;
     const size_t n = (size_t)B * C * h * w;
     if (capacity < n) return fail(TS2D_ERR_INVALID, "tensor '%s' needs %zu floats, capacity is %zu", name, n, capacity);

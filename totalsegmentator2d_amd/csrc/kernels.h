@@ -74,8 +74,8 @@ constexpr int kBM = 256;      // output pixels per workgroup tile
 // ------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain).
 //   GEMM view: M = output pixels, N = output channels, K = TAPS * Cin.
-//   TAPS = 9 : Conv2d 3x3 pad 1 stride STRIDE       (virtual concat via src0/src1)
-//   TAPS = 1 : ConvTranspose2d 2x2 stride 2 as a GEMM with N = 4*Cout (tap (a,b) = n / Cout)   
+//   TAPS = 9 : Conv2d 3x3 pad 1 stride (SY, SX)     (virtual concat via src0/src1)
+//   TAPS = 1 : ConvTranspose2d kernel = stride = (KA, KB) as a GEMM with N = KA*KB*Cout (tap (a,b) = n / Cout)   
 // Workgroup tile: 256 pixels = NIMG images x TH x TW (powers of two) x BN channels; wave w owns pixels
 // [64w, 64w+64) = 2 MFMA row tiles, all BN columns.  Per Cin chunk of CK channels the (haloed) input patch is
 // staged ONCE into LDS (normalised + activated on the way) and reused by all taps.
@@ -97,6 +97,7 @@ struct ConvArgs {
     int lg_nct, lg_tx, lg_tpi;   // log2 of n_ctiles / tiles_x / tiles_x*tiles_y when a power of two, else -1 (the one-image kernels
                                  // decode their block index with shifts and are only launched when all three are >= 0)
     int PH, PW;           // staged patch dims per image
+    int KA, KB;           // transposed conv (conv_mfma_f32, TAPS == 1): kernel = stride (along H, along W); N = KA * KB * Cout
     float slope;
     const void* wph;      // split-fp16 packed weights [chunk][tap][N][16 hi | 16 lo] (f16x3 kernel only)
     int ksplit;           // split-K: blockIdx.y = K slice; slice s writes un-biased partials to dst + s * kslice_stride
@@ -108,17 +109,35 @@ struct ConvArgs {
                           // travels with the multi-GPU weight broadcast (f16x3 kernel only)
 };
 
-template <int STRIDE, int CK>
+template <int SY, int SX, int CK>
 struct ConvCfg {
-    static constexpr int MAXP = (STRIDE == 1) ? 576 : 1296;                 // max patch pixels (16 images of 4x4)
+    static constexpr int MAXP = (SY == 1 && SX == 1) ? 576 : 1296;          // max patch pixels (16 images of 4x4)
     static constexpr int MAXIT = (MAXP * (CK / 4) + kBlock - 1) / kBlock;   // staging iterations per thread
 };
 
-template <int TAPS, int STRIDE, int CK, int BN, int EPI>
+// Activation STORAGE type ST: float (the fp32-parity modes) or _Float16 ("mixed fp16": fp16 storage).
+template <typename ST> __device__ __forceinline__ float round_act(float v) { return (float)(ST)v; }
+template <typename ST> __device__ __forceinline__ void store_act(void* base, size_t off, float v) { reinterpret_cast<ST*>(base)[off] = (ST)v; }
+template <typename ST> __device__ __forceinline__ f32x4 load_act4(const void* base, size_t off);
+template <> __device__ __forceinline__ f32x4 load_act4<float>(const void* base, size_t off) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
+}
+template <> __device__ __forceinline__ f32x4 load_act4<_Float16>(const void* base, size_t off) {
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    const half4_t hv = *reinterpret_cast<const half4_t*>(reinterpret_cast<const _Float16*>(base) + off);
+    return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+}
+
+// SY, SX: stride along H / W (1 or 2 each: nnU-Net pools every axis separately, so a plan may end in (2, 1) / (1, 2) stages; those -
+// in every precision mode - and the whole exact mode run here).  ST = _Float16: the arithmetic CONTRACT of the 16-bit mode on the fp32
+// matrix core (operands rounded to fp16 - weights once, activations after the normalisation, LeakyReLU in fp16 - fp32 accumulation,
+// output stored as fp16, statistics of the stored values).  TAPS == 1: ConvTranspose2d with kernel = stride = (a.KA, a.KB).
+template <int TAPS, int SY, int SX, int CK, int BN, int EPI, typename ST = float>
 __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
     constexpr int KK = CK / 8, NT = BN / 32, PSTR = CK + 4, QPP = CK / 4;
     constexpr int PAD = (TAPS == 9) ? 1 : 0;
-    constexpr int MAXIT = ConvCfg<STRIDE, CK>::MAXIT;
+    constexpr int MAXIT = ConvCfg<SY, SX, CK>::MAXIT;
+    constexpr bool F16 = sizeof(ST) == 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     // ---- XCD-aware block -> tile map: blocks b and b+8 share an XCD (and its L2); consecutive blocks of one
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
             const int pp = idx / QPP;
             const int il = pp / PHW, rem = pp - il * PHW;
             const int py = rem / a.PW, px = rem - py * a.PW;
-            const int n = nimg0 + il, iy = ty0 * STRIDE - PAD + py, ix = tx0 * STRIDE - PAD + px;
+            const int n = nimg0 + il, iy = ty0 * SY - PAD + py, ix = tx0 * SX - PAD + px;
             if (n < a.B && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) g = (n * a.Hin + iy) * a.Win + ix;
             imgbits |= (unsigned long long)il << (4 * it);
         }
@@ -172,7 +191,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
         const int m = 64 * w + 32 * mt + r;
         const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
         // rows past the tile's NIMG*TH*TW pixels (tiny images: NIMG is capped at 16) read a valid dummy address
-        abase[mt] = (il < NIMG ? (il * PHW + ty * STRIDE * a.PW + tx * STRIDE) * PSTR : 0) + 4 * h;
+        abase[mt] = (il < NIMG ? (il * PHW + ty * SY * a.PW + tx * SX) * PSTR : 0) + 4 * h;
     }
     const int bbase = r * 8 + 4 * h;
 
@@ -199,7 +218,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {
                 v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (goff[it] >= 0) v[it] = *reinterpret_cast<const f32x4*>(src + (size_t)goff[it] * C + coff);
+                if (goff[it] >= 0) v[it] = load_act4<ST>(src, (size_t)goff[it] * C + coff);
             }
             if (sc != nullptr) {
                 f32x4 s1 = f32x4{1.f, 1.f, 1.f, 1.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -216,8 +235,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
                             s2 = *reinterpret_cast<const f32x4*>(sh + (size_t)n * C + coff);
                         }
                         f32x4 t = v[it] * s1 + s2;
+                        if constexpr (F16) {      // the operand the 16-bit mode multiplies: fp16(normalised), LeakyReLU in fp16
+                            const float sl = (float)(_Float16)a.slope;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : t[e] * a.slope;
+                            for (int e = 0; e < 4; ++e) { const float y = (float)(_Float16)t[e]; t[e] = fmaxf(y, (float)(_Float16)(y * sl)); }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : t[e] * a.slope;
+                        }
                         v[it] = t;
                     }
                 }
@@ -237,8 +262,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
                 const int idx = tid + it * kBlock;
                 if (idx < W4) {
                     const int tk = idx / (BN * 2), rr = idx - tk * (BN * 2);
-                    *reinterpret_cast<f32x4*>(sB + idx * 4) =
-                        *reinterpret_cast<const f32x4*>(wsrc + (size_t)tk * a.N * 8 + rr * 4);
+                    f32x4 wv = *reinterpret_cast<const f32x4*>(wsrc + (size_t)tk * a.N * 8 + rr * 4);
+                    if constexpr (F16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) wv[e] = (float)(_Float16)wv[e];
+                    }
+                    *reinterpret_cast<f32x4*>(sB + idx * 4) = wv;
                 }
             }
         }
@@ -286,9 +315,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
     for (int nt = 0; nt < NT; ++nt) {
         const int col = n0col + nt * 32 + r;
         int co = col, oa = 0, ob = 0;
-        if (EPI == 1) { const int ab = (n0col + nt * 32) / a.Cout; co = col - ab * a.Cout; oa = ab >> 1; ob = ab & 1; }
+        if (EPI == 1) { const int ab = (n0col + nt * 32) / a.Cout; co = col - ab * a.Cout; oa = ab / a.KB; ob = ab - oa * a.KB; }
         const float bv = a.bias[co];
-        const float kv = stat_pivot(acc_t[0][nt][0] + bv);      // (a pixel outside the image is still a finite value: fine as a pivot)
+        const float kv = stat_pivot(round_act<ST>(acc_t[0][nt][0] + bv));      // (a pixel outside the image is still a finite value: fine as a pivot)
         st_k[nt] = kv;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -301,11 +330,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
                 if (il < NIMG && n < a.B && oy < a.Ht && ox < a.Wt) {
                     const float v = acc_t[mt][nt][i] + bv;
                     if (EPI == 0) {
-                        a.dst[((size_t)(n * a.Ht + oy) * a.Wt + ox) * a.Cout + co] = v;
-                        const float d = v - kv;
+                        store_act<ST>(a.dst, ((size_t)(n * a.Ht + oy) * a.Wt + ox) * a.Cout + co, v);
+                        const float d = round_act<ST>(v) - kv;                 // statistics of what is stored
                         st_s[nt] += d; st_q[nt] = __builtin_fmaf(d, d, st_q[nt]); st_n[nt] += 1.f;
                     } else {
-                        a.dst[((size_t)(n * 2 * a.Ht + 2 * oy + oa) * (2 * a.Wt) + 2 * ox + ob) * a.Cout + co] = v;
+                        store_act<ST>(a.dst, ((size_t)(n * a.KA * a.Ht + a.KA * oy + oa) * (a.KB * a.Wt) + a.KB * ox + ob) * a.Cout + co, v);
                     }
                 }
             }

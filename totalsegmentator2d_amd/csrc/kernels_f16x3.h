@@ -43,8 +43,7 @@ template <> struct Raw8<_Float16> {
         for (int e = 0; e < 4; ++e) { va[e] = (float)h[e]; vb[e] = (float)h[e + 4]; }
     }
 };
-template <typename ST> __device__ __forceinline__ float round_act(float v) { return (float)(ST)v; }
-template <typename ST> __device__ __forceinline__ void store_act(void* base, size_t off, float v) { reinterpret_cast<ST*>(base)[off] = (ST)v; }
+// (round_act / store_act: kernels.h)
 
 
 // fp32 x 8 -> fp16 hi[8] + lo[8] with x = hi + lo to 22 bits: hi = RNE(x) by v_cvt_pk_f16_f32, lo = RNE(x - hi) by ONE mixed-precision

@@ -28,6 +28,8 @@ def _desc(arch: UNetArch) -> _lib.ArchDesc:
     for i, c in enumerate(arch.n_conv_per_stage_decoder):
         d.n_conv_dec[i] = int(c)
     d.norm_eps, d.leaky_slope = arch.norm_eps, arch.leaky_slope
+    for i, st in enumerate(arch.strides):
+        d.strides[i][0], d.strides[i][1] = int(st[0]), int(st[1])
     return d
 
 
