@@ -609,25 +609,80 @@ int upload_weights(ts2d_engine* e, const float* blob, size_t n_floats) {
 }
 
 inline int ct_total(const Op& op) { return op.cin + op.cin_skip; }
+inline int lg_exact(int v) { return (v > 0 && (v & (v - 1)) == 0) ? ilog2(v) : -1; }
 
-struct TileGeom { int lgTH, lgTW, lgNIMG, tiles_x, tiles_y, n_mtiles, PH, PW; };
+// Pixel tiling of one level: tile = NIMG images x TH x TW pixels, NIMG * TH * TW <= 256 (a workgroup's 256 GEMM rows).
+struct TileGeom { int TH, TW, NIMG, lgTH, lgTW, tiles_x, tiles_y, n_mtiles, PH, PW; };
 
-TileGeom tile_geom(int B, int Ht, int Wt, int sy, int sx, int taps) {
-    TileGeom g{};
-    const int TW = std::min(32, pow2ceil(Wt));
-    const int TH = std::min(pow2ceil(Ht), kBM / TW);
-    int NIMG = std::min(16, kBM / (TH * TW));
-    if (Wt > TW || Ht > TH) NIMG = 1;     // several images share a tile only when a whole image fits in it; a short, wide image
-                                          // (Ht < 8 at some level, Wt > 32) gets tiles of TH x 32 < 256 pixels and idle tile rows
-    g.lgTH = ilog2(TH); g.lgTW = ilog2(TW); g.lgNIMG = ilog2(NIMG);
-    if (NIMG > 1) { g.tiles_x = 1; g.tiles_y = 1; }
-    else { g.tiles_x = (Wt + TW - 1) / TW; g.tiles_y = (Ht + TH - 1) / TH; }
-    const int groups = (B + NIMG - 1) / NIMG;
-    g.n_mtiles = groups * g.tiles_x * g.tiles_y;
+inline void tile_finish(TileGeom& g, int B, int Ht, int Wt, int sy, int sx, int taps) {
+    const bool p2 = lg_exact(g.TH) >= 0 && lg_exact(g.TW) >= 0;
+    g.lgTH = p2 ? ilog2(g.TH) : -1; g.lgTW = p2 ? ilog2(g.TW) : -1;
+    if (g.NIMG > 1) { g.tiles_x = 1; g.tiles_y = 1; }
+    else { g.tiles_x = (Wt + g.TW - 1) / g.TW; g.tiles_y = (Ht + g.TH - 1) / g.TH; }
+    g.n_mtiles = (B + g.NIMG - 1) / g.NIMG * g.tiles_x * g.tiles_y;
     const int halo = (taps == 9) ? 3 : 1;
-    g.PH = (TH - 1) * sy + halo; g.PW = (TW - 1) * sx + halo;
+    g.PH = (g.TH - 1) * sy + halo; g.PW = (g.TW - 1) * sx + halo;
+}
+
+// Rounds 1-4: power-of-two tiles (TW = min(32, pow2ceil(Wt)) ...) - complete on 512^2 / 1024^2, idle rows everywhere else.  Kept for
+// the first block (level 0 of a real plan is a multiple of 64 or more along both axes) and as the first candidate below.
+TileGeom tile_geom_pow2(int B, int Ht, int Wt, int sy, int sx, int taps) {
+    TileGeom g{};
+    g.TW = std::min(32, pow2ceil(Wt));
+    g.TH = std::min(pow2ceil(Ht), kBM / g.TW);
+    g.NIMG = std::min(16, kBM / (g.TH * g.TW));
+    if (Wt > g.TW || Ht > g.TH) g.NIMG = 1;   // several images share a tile only when a whole image fits in it
+    tile_finish(g, B, Ht, Wt, sy, sx, taps);
     return g;
 }
+
+// Round 5: the tile shape follows the level's extent (the reference runs whatever patch size plans.json names -
+// ts2d/core/inference/prediction_worker.py:76-77 - and nnU-Net patches such as 640 x 384 or 448 x 576 give levels of 80 x 48, 40 x 24,
+// 56 x 72, 28 x 36 pixels).  The power-of-two tiling is kept when it is waste-free (bit-compatible with rounds 1-4 on 512^2 / 1024^2);
+// otherwise: whole images per tile when at least two fit (any extent: 5 x 6, 10 x 6 ...), else the TH x TW <= 256 with the fewest
+// tiles per image whose haloed patch fits the staging budget of EVERY kernel that may serve the op in any precision mode (the
+// shape depends on (Ht, Wt, stride) only - never on B or on the mode, so the statistics partials are laid out the same everywhere).
+TileGeom tile_geom(int B, int Ht, int Wt, int sy, int sx, int taps) {
+    TileGeom g = tile_geom_pow2(B, Ht, Wt, sy, sx, taps);
+    if (g.NIMG == 1 ? (Ht % g.TH == 0 && Wt % g.TW == 0) : (g.TH == Ht && g.TW == Wt)) return g;
+    const int halo = (taps == 9) ? 3 : 1;
+    auto patch = [&](int th, int tw) { return ((th - 1) * sy + halo) * ((tw - 1) * sx + halo); };
+    const bool s1 = sy == 1 && sx == 1;
+    // staging budgets (patch pixels): conv_mfma_f32 576 / 1296 (ConvCfg::MAXP), conv3x3_f16x3 640, conv3x3s2_f16x3 1536; preferred (one-image
+    // kernels): conv3x3_f16x3_one / conv3x3_h32 384, conv3x3s2_f16x3_one 1280
+    const int hard = taps == 1 ? (1 << 30) : (s1 ? 576 : 1296), soft = taps == 1 ? (1 << 30) : (s1 ? 384 : 1280);
+    if (Ht * Wt * 2 <= kBM) {
+        int n = std::min(16, kBM / (Ht * Wt));
+        while (n > 1 && n * patch(Ht, Wt) > hard) --n;
+        if (n > 1) { g.TH = Ht; g.TW = Wt; g.NIMG = n; tile_finish(g, B, Ht, Wt, sy, sx, taps); return g; }
+    }
+    int best_th = 0, best_tw = 0; long best_cost = -1;
+    for (int pass = 0; pass < 2 && best_cost < 0; ++pass) {
+        const int lim = pass == 0 ? soft : hard;
+        for (int tw = std::min(Wt, kBM); tw >= 1; --tw) {
+            int th = std::min(Ht, kBM / tw);
+            while (th > 1 && patch(th, tw) > lim) --th;
+            if (patch(th, tw) > lim) continue;
+            th = (Ht + (Ht + th - 1) / th - 1) / ((Ht + th - 1) / th);      // the smallest TH with the same number of tile rows (even tiles)
+            const long tiles = (long)((Ht + th - 1) / th) * ((Wt + tw - 1) / tw);
+            // fewest tiles; then whole rows of 4 pixels (the 16-byte stores of a lane stay inside a tile row), then the wider tile
+            const long cost = tiles * 4 + (tw % 4 ? 1 : 0);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_th = th; best_tw = tw; }
+        }
+    }
+    g.TH = best_th; g.TW = best_tw; g.NIMG = 1;
+    tile_finish(g, B, Ht, Wt, sy, sx, taps);
+    return g;
+}
+
+// the 8 x 32 / 16 x 32 tilings of the kernels that walk complete tiles of a fixed shape
+TileGeom tile_fixed(int B, int Ht, int Wt, int th, int tw, int sy, int sx) {
+    TileGeom g{};
+    g.TH = th; g.TW = tw; g.NIMG = 1;
+    tile_finish(g, B, Ht, Wt, sy, sx, 9);
+    return g;
+}
+
 
 template <int TAPS, int SY, int SX, int CK, int BN, int EPI, typename ST = float>
 hipError_t launch_conv_inst(const ConvArgs& a, int grid, size_t smem, hipStream_t st) {
@@ -762,41 +817,188 @@ void launch_stats_direct(bool f16, int B, int C, int HW, const float* x, const f
 }
 
 // Split-K factor for a split-fp16 conv whose grid would leave most CUs idle (8x8 / 4x4 bottleneck levels).
-int choose_ksplit(const ts2d_engine* e, const Op& op, int B, int H, int W) {
+int choose_ksplit(const Op& op, const TileGeom& g) {
     if (op.type != OP_CONV || !op.split_ok || op.first_direct) return 1;
-    const TileGeom g = tile_geom(B, H >> op.ly, W >> op.lx, op.sy, op.sx, 9);
     // The factor depends on the layer geometry only (never on B), so a slice computes bit-identically alone or in a batch:
     // tiles that hold >= 4 whole images (<= 8x8 pixels per image) leave most CUs idle -> split K as far as 4 chunks/slice.
-    (void)B;
-    if (g.lgNIMG < 2) return 1;
+    if (g.NIMG < 4) return 1;
     const int nchunks = (op.cin + op.cin_skip) / (op.stride == 1 ? 16 : 8);
     int S = 1;
     while (S < 8 && nchunks / (S * 2) >= 4) S *= 2;
     return S;
 }
 
+// ------------------------------------------------------------------------------------------------------------------ dispatch
+// ONE function decides which kernel serves an op for (precision, options, B, H, W).  The activation plan (which tensors exist), the
+// workspace sizing and the run (what is launched) all ask it, so they cannot disagree (the eligibility tests
+// used to be written at plan time and again inline at launch; round 3's plan / run mismatch came from exactly that).
+enum Kern { K_NONE = 0, K_FUSED_AWAY, K_FIRST, K_FIRST_STATS, K_EXACT, K_S1_GENERIC, K_S1_ONE, K_S1_QP, K_S1_H32, K_S1_H2, K_S1_RES32, K_S1_RES32F,
+            K_S2_V2, K_S2_ONE, K_S2_GENERIC, K_T_ONE, K_T_GENERIC, K_UP0, K_UPQ, K_UPC, K_UPC_H, K_UPC_H2, K_HEAD_MFMA, K_HEAD_1X1 };
+
+struct Choice {
+    Kern k = K_NONE;
+    TileGeom g{};               // the pixel tiling the kernel walks
+    int bn = 0;                 // output columns per workgroup
+    int ksplit = 1;
+    bool fused_stats = false;   // per-tile partial statistics come out of the kernel's epilogue (else stats_direct / splitk_reduce_stats)
+    bool first_full = false;    // (K_FIRST*) complete one-image 256-pixel tiles: the persistent variant
+};
+
+inline bool fits32(size_t bytes) { return bytes < ((size_t)1 << 31); }      // an image addressed through a 32-bit buffer offset
+
+// Does the first block run as a statistics-only pass, recomputed inside the second block (conv3x3_res32<.., FUSE>)?
+bool fuse0_applies(const ts2d_engine* e, int H, int W) {
+    // (split mode only.  Measured in the 16-bit mode, B = 64 canonical: 0.30 + 0.94 ms fused against 0.44 + 0.52 ms as two kernels - the
+    //  16-bit second block is HBM-bound at a third of the split block's MFMA work, and the recompute is fp32 MFMA work either way)
+    if (!e->use_fuse0 || !e->use_res || !e->use_one || e->precision != TS2D_PRECISION_F32_SPLIT_F16X3 || e->ops.size() < 3) return false;
+    const Op& o0 = e->ops[0]; const Op& o1 = e->ops[1];
+    if (!o0.first_direct || o0.cout != 32 || e->arch.input_channels > 2) return false;
+    if (o1.type != OP_CONV || !o1.res_ok || o1.src != o0.dst || o1.skip >= 0) return false;
+    for (size_t i = 2; i < e->ops.size(); ++i) if (e->ops[i].src == o0.dst || e->ops[i].skip == o0.dst) return false;      // (a one-conv stage: the tensor is a skip)
+    if (H % 8 || W % 32) return false;
+    return fits32((size_t)H * W * 32 * 4) && fits32((size_t)e->arch.input_channels * H * W * 4);
+}
+
+// The decoder block `op` (3x3 conv over cat(up, skip)) as ONE kernel together with its transposed conv (kernels_upc.h ...), or K_NONE.
+Kern composed_kernel(const ts2d_engine* e, const Op& op, int B, int H, int W) {
+    if (!op.upc_ok || !e->use_upc || !e->use_one || e->precision == TS2D_PRECISION_F32_EXACT || B < 1) return K_NONE;
+    const bool f16 = e->precision == TS2D_PRECISION_F16;
+    const Op& up = e->ops[op.up_idx];
+    const bool srcs_normed = e->tensors[up.src].normed && e->tensors[op.skip].normed;       // (`normed`, not the scale POINTERS: the plan asks
+                                                                                           //  before the workspace - and the pointers - exist)
+    if (f16 && (op.cin_skip % 32 || !srcs_normed)) return K_NONE;       // (the 16-bit kernels walk the skip channels in chunks of 32 and normalise both sources)
+    const int Ht = H >> op.ly, Wt = W >> op.lx;
+    if (Ht % 8 || Wt % 32) return K_NONE;                               // complete 8 x 32 tiles
+    if (op.up0_ok && e->use_up0 && srcs_normed && fits32((size_t)Ht * Wt * 32 * 4)) return K_UP0;
+    if (!fits32((size_t)Ht * Wt * std::max(op.cout, op.cin_skip) * 4) || !fits32((size_t)(Ht / 2) * (Wt / 2) * up.cin * 4)) return K_NONE;
+    const int bn = op.cout % 64 == 0 ? 64 : 32;
+    if (f16) return (e->use_uh2 && bn == 64 && Ht % 16 == 0) ? K_UPC_H2 : K_UPC_H;
+    const bool upq = e->use_upq && bn == 64 && up.cin >= e->upq_min && Ht % 16 == 0 && srcs_normed && up.cin <= 512 && op.cin_skip <= 512;
+    return upq ? K_UPQ : K_UPC;           // (Cb = 128: conv3x3_upq no faster than conv3x3_upc, measured)
+}
+
+Choice choose(const ts2d_engine* e, size_t oi, int B, int H, int W) {
+    const Op& op = e->ops[oi];
+    Choice c;
+    const bool f16 = e->precision == TS2D_PRECISION_F16, exact = e->precision == TS2D_PRECISION_F32_EXACT;
+    if (op.type == OP_HEAD) {
+        const bool hm = op.split_ok && !exact && e->use_one && e->tensors[op.src].C == 32 && (H * W) % 32 == 0 && W % 32 == 0;
+        c.k = hm ? K_HEAD_MFMA : K_HEAD_1X1;
+        return c;
+    }
+    if (op.first_direct) {
+        c.g = tile_geom_pow2(B, H, W, 1, 1, 9);
+        const int kp = (op.cin + 1) / 2, P = c.g.PH * c.g.PW * c.g.NIMG;
+        c.fused_stats = c.g.NIMG == 1;
+        c.first_full = c.g.NIMG == 1 && c.g.lgTW >= 4 && c.g.lgTH + c.g.lgTW == 8 && H % c.g.TH == 0 && W % c.g.TW == 0 &&
+                       P * 2 * kp <= 4 * kBlock && fits32((size_t)H * W * op.cout * 4);
+        c.k = fuse0_applies(e, H, W) ? K_FIRST_STATS : K_FIRST;
+        return c;
+    }
+    const Tensor& src = e->tensors[op.src];
+    const int Hin = H >> src.ly, Win = W >> src.lx;
+    if (op.type == OP_CONVT) {
+        if (oi + 1 < e->ops.size() && e->ops[oi + 1].up_idx == (int)oi && composed_kernel(e, e->ops[oi + 1], B, H, W) != K_NONE) {
+            c.k = K_FUSED_AWAY;             // composed into the next block: the upsampled tensor is never materialised
+            return c;
+        }
+        c.g = tile_geom(B, Hin, Win, 1, 1, 1);          // (the transposed conv tiles its INPUT pixels)
+        const int N = op.sy * op.sx * op.cout;
+        if (!(op.split_ok && !exact)) {                 // exact mode, or a kernel other than 2 x 2: the generic kernel in every mode
+            if (f16 && op.stride == 2) return c;        // (K_NONE: a 2 x 2 transposed conv without a 16-bit kernel - Cin % 32 != 0)
+            c.k = K_EXACT; c.bn = (N % 64 == 0 && op.cout % 64 == 0) ? 64 : 32;
+            return c;
+        }
+        c.bn = 64;                                      // N = 4 * Cout is a multiple of 128; each 32-column tile lies in one (a, b) tap
+        c.k = (e->use_one && c.g.NIMG == 1 && fits32((size_t)4 * Hin * Win * op.cout * 4) && fits32((size_t)Hin * Win * op.cin * 4)) ? K_T_ONE : K_T_GENERIC;
+        return c;
+    }
+    const int Ht = H >> op.ly, Wt = W >> op.lx, ct = ct_total(op);
+    if (op.up_idx >= 0) {
+        const Kern ck = composed_kernel(e, op, B, H, W);
+        if (ck != K_NONE) {
+            c.k = ck; c.fused_stats = true;
+            c.bn = op.cout % 64 == 0 ? 64 : 32;
+            c.g = tile_fixed(B, Ht, Wt, (ck == K_UPQ || ck == K_UPC_H2) ? 16 : 8, 32, 1, 1);
+            return c;
+        }
+    }
+    c.bn = op.cout % 64 == 0 ? 64 : 32;
+    if (!(op.split_ok && !exact)) {
+        if (f16 && op.stride != 3) return c;            // (K_NONE: no 16-bit kernel - channel counts must be multiples of 16)
+        c.k = K_EXACT;
+        c.g = tile_geom(B, Ht, Wt, op.sy, op.sx, 9);
+        c.fused_stats = c.g.NIMG == 1;
+        return c;
+    }
+    const bool img32 = fits32((size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4) && fits32((size_t)Ht * Wt * op.cout * 4);
+    if (op.stride == 2) {
+        if (op.s2v2_ok && e->use_s2v2 && e->use_one && Ht % 8 == 0 && Wt % 32 == 0 && img32) {
+            // stride-2 block on complete 8 x 32 output tiles: one 512-thread workgroup per CU, up to 128 output columns
+            c.k = K_S2_V2; c.bn = op.bn2; c.fused_stats = true;
+            c.g = tile_fixed(B, Ht, Wt, 8, 32, 2, 2);
+            return c;
+        }
+        c.g = tile_geom(B, Ht, Wt, 2, 2, 9);
+        c.ksplit = choose_ksplit(op, c.g);
+        c.fused_stats = c.g.NIMG == 1;
+        const int P = c.g.PH * c.g.PW * c.g.NIMG;
+        c.k = (e->use_one && c.g.NIMG == 1 && P <= 5 * kBlock && img32) ? K_S2_ONE : K_S2_GENERIC;
+        return c;
+    }
+    if (op.res_ok && e->use_res && e->use_one && src.normed && op.skip < 0 && Ht % 8 == 0 && Wt % 32 == 0 && fits32((size_t)Ht * Wt * 32 * 4)) {
+        // 32 -> 32 stride-1 block on complete 8 x 32 tiles: persistent kernel with the layer's weights resident in LDS
+        c.k = (oi == 1 && fuse0_applies(e, H, W)) ? K_S1_RES32F : K_S1_RES32;
+        c.fused_stats = true;
+        c.g = tile_fixed(B, Ht, Wt, 8, 32, 1, 1);
+        return c;
+    }
+    c.g = tile_geom(B, Ht, Wt, 1, 1, 9);
+    c.ksplit = choose_ksplit(op, c.g);
+    c.fused_stats = c.g.NIMG == 1;
+    const int P = c.g.PH * c.g.PW * c.g.NIMG;
+    const bool srcs_normed = src.normed && (op.skip < 0 || e->tensors[op.skip].normed);
+    const bool tiles16 = Ht % 16 == 0 && Wt % 32 == 0 && c.g.NIMG == 1 && img32;          // complete 16 x 32 tiles
+    if (f16) {
+        if (e->use_h2 && tiles16 && op.cout % 64 == 0 && op.skip < 0 && ct % 32 == 0 && src.normed && ct >= e->h2_min) {
+            c.k = K_S1_H2; c.bn = 64;       // plain C -> C block on 16 x 32 tiles: the skip phase of conv3x3_upc_h2
+            c.g = tile_fixed(B, Ht, Wt, 16, 32, 1, 1);
+            return c;
+        }
+        c.k = (op.h32_ok && e->use_h32 && c.g.NIMG == 1 && P * 4 <= 6 * kBlock && img32) ? K_S1_H32 : K_S1_GENERIC;
+        return c;
+    }
+    const bool one = e->use_one && c.g.NIMG == 1 && P * 2 <= 3 * kBlock && img32;
+    if (one && e->use_q && tiles16 && c.bn == 64 && ct >= 64 && srcs_normed) {       // (pays off from 4 chunks on: measured)
+        c.k = K_S1_QP;                      // one persistent 512-thread workgroup per CU, patch and weights double-buffered
+        c.g = tile_fixed(B, Ht, Wt, 16, 32, 1, 1);
+        return c;
+    }
+    c.k = one ? K_S1_ONE : K_S1_GENERIC;
+    return c;
+}
+
 size_t partial_floats_needed(const ts2d_engine* e, int B, int H, int W) {
     size_t mx = 0;
-    for (const Op& op : e->ops) {
-        const int S = choose_ksplit(e, op, B, H, W);
-        if (S > 1) mx = std::max(mx, (size_t)S * B * (H >> op.ly) * (W >> op.lx) * op.cout);
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        const Op& op = e->ops[i];
+        const Choice c = choose(e, i, B, H, W);
+        if (c.ksplit > 1) mx = std::max(mx, (size_t)c.ksplit * B * (H >> op.ly) * (W >> op.lx) * op.cout);
     }
     return mx;
 }
 
 size_t part_floats_needed(const ts2d_engine* e, int B, int H, int W) {
     size_t mx = 0;
-    for (const Op& op : e->ops) {
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        const Op& op = e->ops[i];
         if (op.type != OP_CONV) continue;
-        const int Ht = H >> op.ly, Wt = W >> op.lx;
-        TileGeom g = tile_geom(B, Ht, Wt, op.sy, op.sx, 9);
-        if (g.lgNIMG == 0) mx = std::max(mx, (size_t)B * g.tiles_x * g.tiles_y * op.cout * 4);      // (S, Q, K, n) per (tile, channel)
+        const Choice c = choose(e, i, B, H, W);
+        if (c.fused_stats) mx = std::max(mx, (size_t)B * c.g.tiles_x * c.g.tiles_y * op.cout * 4);      // (S, Q, K, n) per (tile, channel)
     }
     return mx;
 }
 
-bool upc_applies(const ts2d_engine* e, const Op& op, int B, int H, int W);
-bool fuse0_applies(const ts2d_engine* e, int H, int W);
 
 // Activation plan (round 3): liveness-based reuse.  An activation lives from the op that writes it to the last op that reads it
 // (the encoder skips until their decoder block); its bytes then return to a first-fit free list inside ONE arena, sized by
@@ -816,7 +1018,7 @@ ActPlan plan_activations(const ts2d_engine* e, int B, int H, int W, bool keep) {
     for (size_t i = 0; i < no; ++i) {
         const Op& op = e->ops[i];
         if (fused0 && i == 1) continue;                    // (reads the network input, which is not part of the arena)
-        if (op.type == OP_CONVT && i + 1 < no && e->ops[i + 1].up_idx == (int)i && upc_applies(e, e->ops[i + 1], B, H, W)) { skipped[i] = 1; continue; }
+        if (op.type == OP_CONVT && choose(e, i, B, H, W).k == K_FUSED_AWAY) { skipped[i] = 1; continue; }
         if (op.type == OP_CONV && op.up_idx >= 0 && skipped[op.up_idx]) { reads[i] = {e->ops[op.up_idx].src, op.skip}; continue; }
         if (!(op.first_direct)) reads[i].push_back(op.src);
         if (op.skip >= 0) reads[i].push_back(op.skip);
@@ -992,42 +1194,13 @@ int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d
     return rc != TS2D_OK ? rc : rc2;
 }
 
-// Does the decoder block `op` (3x3 conv over cat(up, skip)) run as ONE kernel together with its transposed conv for this geometry?
-// (the activation plan of ensure_workspace relies on the SAME answer at run time: it depends on (precision, H, W) only)
-// ... and as the dedicated level-0 kernel (kernels_up0.h)?  Ht x Wt: the block's output extent (complete 8 x 32 tiles).
-bool up0_applies(const ts2d_engine* e, const Op& op, int Ht, int Wt) {
-    return op.up0_ok && e->use_up0 && Ht % 8 == 0 && Wt % 32 == 0 && (size_t)Ht * Wt * 32 * 4 < ((size_t)1 << 31) &&
-           e->tensors[e->ops[op.up_idx].src].normed && e->tensors[op.skip].normed;       // (`normed`, not the scale POINTERS: the activation
-           // plan asks this question before the workspace - and with it the pointers - exists; a plan made for the two-kernel path and
-           // a run that composes would place the block's output on a buffer the run still reads)
-}
-
-// Does the first block run as a statistics-only pass, recomputed inside the second block (conv3x3_res32<.., FUSE>)?  Depends on
-// (options, precision, H, W) only - the activation plan asks the same question.
-bool fuse0_applies(const ts2d_engine* e, int H, int W) {
-    // (split mode only.  Measured in the 16-bit mode, B = 64 canonical: 0.30 + 0.94 ms fused against 0.44 + 0.52 ms as two kernels - the
-    //  16-bit second block is HBM-bound at a third of the split block's MFMA work, and the recompute is fp32 MFMA work either way)
-    if (!e->use_fuse0 || !e->use_res || !e->use_one || e->precision != TS2D_PRECISION_F32_SPLIT_F16X3 || e->ops.size() < 3) return false;
-    const Op& o0 = e->ops[0]; const Op& o1 = e->ops[1];
-    if (!o0.first_direct || o0.cout != 32 || e->arch.input_channels > 2) return false;
-    if (o1.type != OP_CONV || !o1.res_ok || o1.src != o0.dst || o1.skip >= 0) return false;
-    for (size_t i = 2; i < e->ops.size(); ++i) if (e->ops[i].src == o0.dst || e->ops[i].skip == o0.dst) return false;      // (a one-conv stage: the tensor is a skip)
-    if (H % 8 || W % 32) return false;
-    return (size_t)H * W * 32 * 4 < ((size_t)1 << 31) && (size_t)e->arch.input_channels * H * W * 4 < ((size_t)1 << 31);
-}
-
-bool upc_applies(const ts2d_engine* e, const Op& op, int B, int H, int W) {
-    if (!op.upc_ok || !e->use_upc || !e->use_one || e->precision == TS2D_PRECISION_F32_EXACT) return false;
-    if (e->precision == TS2D_PRECISION_F16 && (op.cin_skip % 32 || !e->tensors[e->ops[op.up_idx].src].normed || !e->tensors[op.skip].normed))
-        return false;                       // (the 16-bit kernel walks the skip channels in chunks of 32 and normalises both sources)
-    const int Ht = H >> op.ly, Wt = W >> op.lx;
-    if (Ht % 8 || Wt % 32) return false;
-    if (up0_applies(e, op, Ht, Wt)) return B > 0;       // (walks its tiles by division: any tile count)
-    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    const int bn = op.cout % 64 == 0 ? 64 : 32;
-    if (!pow2(Wt / 32) || !pow2((Wt / 32) * (Ht / 8)) || !pow2(op.cout / bn)) return false;
-    const size_t lim = (size_t)1 << 31;
-    return (size_t)Ht * Wt * std::max(op.cout, op.cin_skip) * 4 < lim && (size_t)(Ht / 2) * (Wt / 2) * e->ops[op.up_idx].cin * 4 < lim && B > 0;
+// ConvArgs fields that describe the pixel tiling / the (tile, column tile) grid
+inline void set_tiling(ConvArgs& ca, const TileGeom& g, int n_ctiles) {
+    ca.TH = g.TH; ca.TW = g.TW; ca.NIMG = g.NIMG; ca.lgTH = g.lgTH; ca.lgTW = g.lgTW;
+    ca.inv_tw = 1.0f / (float)g.TW; ca.inv_thw = 1.0f / (float)(g.TH * g.TW);
+    ca.tiles_x = g.tiles_x; ca.tiles_y = g.tiles_y; ca.n_mtiles = g.n_mtiles; ca.n_ctiles = n_ctiles;
+    ca.inv_tx = 1.0f / (float)g.tiles_x; ca.inv_tpi = 1.0f / (float)(g.tiles_x * g.tiles_y); ca.inv_nct = 1.0f / (float)n_ctiles;
+    ca.PH = g.PH; ca.PW = g.PW;
 }
 
 int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st) {
@@ -1050,29 +1223,44 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
         HIP_TRY(hipGetLastError());
         TRY(prof_end(e, st));
     }
-    for (const Op& op : e->ops) {
+    const float* wts = e->d_weights;
+    for (size_t oi = 0; oi < e->ops.size(); ++oi) {
+        const Op& op = e->ops[oi];
         const Tensor& src = e->tensors[op.src];
-        const float* wts = e->d_weights;
-        if (op.first_direct) {
+        const Choice c = choose(e, oi, B, H, W);
+        const TileGeom& g = c.g;
+        unsigned long long* const prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
+        // per-tile partials -> scale / shift of the op's output (the launches of an op end with it)
+        auto finalize = [&](int Ht, int Wt) -> int {
             Tensor& dst = e->tensors[op.dst];
-            const TileGeom g = tile_geom(B, H, W, 1, 1, 9);
+            TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
+            launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
+                            op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+            HIP_TRY(hipGetLastError());
+            return prof_end(e, st);
+        };
+        switch (c.k) {
+        case K_NONE:
+            return fail(TS2D_ERR_INVALID, "op %s has no fp16 kernel (channel counts must be multiples of 16)", op.name.c_str());
+        case K_FUSED_AWAY:
+            e->fused_away[oi] = 1;          // composed into the next block (kernels_upc.h): the upsampled tensor is never materialised
+            break;
+        case K_FIRST: case K_FIRST_STATS: {
+            Tensor& dst = e->tensors[op.dst];
             FirstArgs fa{};
             fa.x = d_in; fa.w = wts + op.dev_wraw; fa.bias = wts + op.dev_b; fa.dst = dst.data;
-            const bool fused = g.lgNIMG == 0;
-            fa.part = fused ? e->d_part : nullptr;
+            fa.part = c.fused_stats ? e->d_part : nullptr;
             fa.B = B; fa.C = op.cin; fa.H = H; fa.W = W; fa.Cout = op.cout;
-            fa.lgTH = g.lgTH; fa.lgTW = g.lgTW; fa.lgNIMG = g.lgNIMG; fa.tiles_x = g.tiles_x; fa.tiles_y = g.tiles_y;
+            fa.lgTH = g.lgTH; fa.lgTW = g.lgTW; fa.lgNIMG = ilog2(g.NIMG); fa.tiles_x = g.tiles_x; fa.tiles_y = g.tiles_y;
             fa.n_mtiles = g.n_mtiles; fa.PH = g.PH; fa.PW = g.PW;
-            const int kp = (op.cin + 1) / 2, nt = op.cout / 32, P = (g.PH * g.PW) << g.lgNIMG;
+            const int kp = (op.cin + 1) / 2, nt = op.cout / 32, P = g.PH * g.PW * g.NIMG;
             const size_t smem = std::max((size_t)P * (2 * kp + 1) * sizeof(float), (size_t)4 * op.cout * 4 * sizeof(float));
             TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_first");
             // complete one-image 256-pixel tiles everywhere: persistent workgroups (4 per CU) with the next tile's patch in flight
-            const bool first_full = g.lgNIMG == 0 && g.lgTH + g.lgTW == 8 && g.lgTW >= 4 && H % (1 << g.lgTH) == 0 && W % (1 << g.lgTW) == 0 &&
-                                    P * 2 * kp <= 4 * kBlock && (size_t)H * W * op.cout * 4 < ((size_t)1 << 31);
+            const bool first_full = c.first_full;
             const int grid_first = first_full ? std::min(g.n_mtiles, e->num_cus * (nt == 1 ? 4 : 2)) : g.n_mtiles;
-            const bool stats_only = fuse0_applies(e, H, W);           // (implies first_full geometry, nt == 1, kp == 1)
-            if (stats_only) {
-                if (!first_full || !fused) return fail(TS2D_ERR_INVALID, "internal: fused first block on a geometry without complete tiles");
+            if (c.k == K_FIRST_STATS) {        // statistics only; the block is recomputed inside the second one (implies first_full, nt == 1, kp == 1)
+                if (!first_full || !c.fused_stats) return fail(TS2D_ERR_INVALID, "internal: fused first block on a geometry without complete tiles");
                 prof_kernel(e, "conv3x3_first_stats");
                 if (f16) hipLaunchKernelGGL((conv3x3_first<1, 1, _Float16, true, false>), dim3(grid_first), dim3(kBlock), smem, st, fa);
                 else hipLaunchKernelGGL((conv3x3_first<1, 1, float, true, false>), dim3(grid_first), dim3(kBlock), smem, st, fa);
@@ -1083,64 +1271,52 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                                   else hipLaunchKernelGGL((conv3x3_first<NT_, KP_, float, true>), dim3(grid_first), dim3(kBlock), smem, st, fa); } \
                 else { if (f16) hipLaunchKernelGGL((conv3x3_first<NT_, KP_, _Float16, false>), dim3(grid_first), dim3(kBlock), smem, st, fa); \
                        else hipLaunchKernelGGL((conv3x3_first<NT_, KP_, float, false>), dim3(grid_first), dim3(kBlock), smem, st, fa); } } while (0)
-            if (stats_only) {}
             else if (nt == 1 && kp == 1) TS2D_FIRST(1, 1);
             else if (nt == 1 && kp == 2) TS2D_FIRST(1, 2);
             else if (nt == 2 && kp == 1) TS2D_FIRST(2, 1);
             else if (nt == 2 && kp == 2) TS2D_FIRST(2, 2);
             else return fail(TS2D_ERR_INVALID, "first block: unsupported Cout %d / Cin %d", op.cout, op.cin);
+#undef TS2D_FIRST
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
-            TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
-            if (fused)
-                launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
-                                   op.cout, B, H * W, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
-            else
+            if (c.fused_stats) TRY(finalize(H, W));
+            else {
+                TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
                 launch_stats_direct(f16, B, op.cout, H * W, dst.data, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift, st);
-            HIP_TRY(hipGetLastError());
-            TRY(prof_end(e, st));
-            continue;
+                HIP_TRY(hipGetLastError());
+                TRY(prof_end(e, st));
+            }
+            break;
         }
-        const size_t oi = (size_t)(&op - e->ops.data());
-        if (op.type == OP_CONVT && oi + 1 < e->ops.size() && e->ops[oi + 1].up_idx == (int)oi && upc_applies(e, e->ops[oi + 1], B, H, W)) {
-            e->fused_away[oi] = 1;          // composed into the next block (kernels_upc.h): the upsampled tensor is never materialised
-            continue;
-        }
-        if (op.type == OP_CONV && op.up_idx >= 0 && e->fused_away[op.up_idx]) {
+        case K_UP0: case K_UPQ: case K_UPC: case K_UPC_H: case K_UPC_H2: {
             const Op& up = e->ops[op.up_idx];
             const Tensor& xc = e->tensors[up.src]; const Tensor& sk = e->tensors[op.skip]; Tensor& dst = e->tensors[op.dst];
-            const int Ht = H >> op.ly, Wt = W >> op.lx, bn = op.cout % 64 == 0 ? 64 : 32;
+            const int Ht = H >> op.ly, Wt = W >> op.lx, bn = c.bn;
             UpcArgs ua{};
             ua.xc = xc.data; ua.scc = xc.scale; ua.shc = xc.shift; ua.Cb = up.cin;
             ua.xs = sk.data; ua.scs = sk.scale; ua.shs = sk.shift; ua.Cs = op.cin_skip;
             ua.wc = wts + op.dev_wc; ua.wk = wts + op.dev_wk; ua.bvar = wts + op.dev_bvar; ua.oscale = wts + op.dev_wcs;
             ua.dst = dst.data; ua.part = e->d_part;
             ua.B = B; ua.H = Ht; ua.W = Wt; ua.Cout = op.cout;
-            ua.tiles_x = Wt / 32; ua.tiles_y = Ht / 8; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y; ua.n_ctiles = op.cout / bn;
-            ua.lg_nct = ilog2(ua.n_ctiles); ua.lg_tx = ilog2(ua.tiles_x); ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
+            ua.tiles_x = g.tiles_x; ua.tiles_y = g.tiles_y; ua.n_mtiles = g.n_mtiles; ua.n_ctiles = op.cout / bn;
             ua.slope = a.leaky_slope;
-            ua.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr; ua.dbg = e->dbg;
+            ua.prof = prof; ua.dbg = e->dbg;
             const int grid = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
-            const size_t smem_u = std::max((size_t)8 * kUcPlane, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
-            auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-            const bool upq = !f16 && e->use_upq && bn == 64 && up.cin >= e->upq_min && Ht % 16 == 0 &&      // (Cb = 128: no faster than conv3x3_upc, measured)
-                             pow2(Wt / 32) && pow2((Wt / 32) * (Ht / 16)) && xc.scale != nullptr &&
-                             sk.scale != nullptr && up.cin <= 512 && op.cin_skip <= 512;
-            const bool up0 = up0_applies(e, op, Ht, Wt);
-            if (up0) {       // level 0: persistent, resident skip weights, 16x16x32 transposed product (kernels_up0.h)
+            TRY(prof_begin(e, op.name, st));
+            if (c.k == K_UP0) {       // level 0: persistent, resident skip weights, 16x16x32 transposed product (kernels_up0.h)
                 Up0Args u0{};
                 u0.xc = xc.data; u0.scc = xc.scale; u0.shc = xc.shift; u0.xs = sk.data; u0.scs = sk.scale; u0.shs = sk.shift;
                 u0.wc0 = wts + op.dev_w0c; u0.wk0 = wts + op.dev_w0k; u0.bvar = wts + op.dev_bvar; u0.oscale = wts + op.dev_wcs;
                 u0.dst = dst.data; u0.part = e->d_part;
-                u0.B = B; u0.H = Ht; u0.W = Wt; u0.tiles_x = Wt / 32; u0.tiles_y = Ht / 8; u0.n_tiles = B * u0.tiles_x * u0.tiles_y;
+                u0.B = B; u0.H = Ht; u0.W = Wt; u0.tiles_x = g.tiles_x; u0.tiles_y = g.tiles_y; u0.n_tiles = g.n_mtiles;
                 u0.slope = a.leaky_slope;
-                u0.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
+                u0.prof = prof;
                 const int tpi0 = u0.tiles_x * u0.tiles_y, want = std::min(u0.n_tiles, 2 * e->num_cus);
                 int seg = 1;          // (segments as conv3x3_res32: the largest divisor of an image's tiles that leaves >= 2 workgroups per CU)
                 for (int d = 1; d <= tpi0; ++d) if (tpi0 % d == 0 && u0.n_tiles / d >= want) seg = d;
                 if (e->u0seg > 0 && tpi0 % e->u0seg == 0) seg = e->u0seg;      // (option "u0seg": tests)
                 u0.seg = seg;
-                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_up0");
+                prof_kernel(e, "conv3x3_up0");
                 if (f16) {
                     static std::atomic<uint64_t> done0h{0};
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_up0<_Float16, 1>), done0h));
@@ -1150,38 +1326,33 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_up0<float, 3>), done0));
                     hipLaunchKernelGGL((conv3x3_up0<float, 3>), dim3(u0.n_tiles / seg), dim3(kBlock), 9 * 2 * 4 * 512 + 8 * kResPS, st, u0);
                 }
-            } else if (f16 && e->use_uh2 && bn == 64 && Ht % 16 == 0 && pow2(Wt / 32) && pow2((Wt / 32) * (Ht / 16))) {
+            } else if (c.k == K_UPC_H2) {
                 // 16-bit mode on 16 x 32 tiles: four M tiles per wave, skip-half weights by DMA (kernels_upc_h2.h)
                 const int ks = up.cin % 64 == 0 ? 4 : 2;
-                ua.tiles_y = Ht / 16; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y;
-                ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
-                const int grid2 = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
-                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_upc_h2");
+                prof_kernel(e, "conv3x3_upc_h2");
                 static std::atomic<uint64_t> doneh4{0}, doneh2{0};
                 if (ks == 4) { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h2<4>), doneh4));
-                               hipLaunchKernelGGL(conv3x3_upc_h2<4>, dim3(grid2), dim3(kBlock), kUh2Lds, st, ua); }
+                               hipLaunchKernelGGL(conv3x3_upc_h2<4>, dim3(grid), dim3(kBlock), kUh2Lds, st, ua); }
                 else { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h2<2>), doneh2));
-                       hipLaunchKernelGGL(conv3x3_upc_h2<2>, dim3(grid2), dim3(kBlock), kUh2Lds, st, ua); }
-            } else if (f16) {       // 16-bit mode: fp16 storage, one product (kernels_upc_h.h)
+                       hipLaunchKernelGGL(conv3x3_upc_h2<2>, dim3(grid), dim3(kBlock), kUh2Lds, st, ua); }
+            } else if (c.k == K_UPC_H) {       // 16-bit mode: fp16 storage, one product (kernels_upc_h.h)
                 const int ks = up.cin % 64 == 0 ? 4 : 2;
                 const size_t smem_h = std::max((size_t)ks * 2 * kUcPlane, (size_t)4 * kUsPlane + (size_t)2 * 9 * 2 * bn * 16);
-                TRY(prof_begin(e, op.name, st)); prof_kernel(e, bn == 64 ? "conv3x3_upc_h<64>" : "conv3x3_upc_h<32>");
+                prof_kernel(e, bn == 64 ? "conv3x3_upc_h<64>" : "conv3x3_upc_h<32>");
 #define TS2D_UPCH(BN_, KS_) do { static std::atomic<uint64_t> done_{0}; \
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h<BN_, KS_>), done_)); \
                     hipLaunchKernelGGL((conv3x3_upc_h<BN_, KS_>), dim3(grid), dim3(kBlock), smem_h, st, ua); } while (0)
                 if (bn == 64) { if (ks == 4) TS2D_UPCH(64, 4); else TS2D_UPCH(64, 2); }
                 else { if (ks == 4) TS2D_UPCH(32, 4); else TS2D_UPCH(32, 2); }
 #undef TS2D_UPCH
-            } else if (upq) {       // 16 x 32 tiles, one 512-thread workgroup per CU, double-buffered staging (kernels_upq.h)
-                ua.tiles_y = Ht / 16; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y;
-                ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
-                const int gridq = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
-                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_upq");
+            } else if (c.k == K_UPQ) {       // 16 x 32 tiles, one 512-thread workgroup per CU, double-buffered staging (kernels_upq.h)
+                prof_kernel(e, "conv3x3_upq");
                 static std::atomic<uint64_t> doneq{0};
                 HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upq), doneq));
-                hipLaunchKernelGGL(conv3x3_upq, dim3(gridq), dim3(kUqThreads), kUqLds, st, ua);
+                hipLaunchKernelGGL(conv3x3_upq, dim3(grid), dim3(kUqThreads), kUqLds, st, ua);
             } else {
-                TRY(prof_begin(e, op.name, st)); prof_kernel(e, bn == 64 ? "conv3x3_upc<64>" : "conv3x3_upc<32>");
+                const size_t smem_u = std::max((size_t)8 * kUcPlane, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
+                prof_kernel(e, bn == 64 ? "conv3x3_upc<64>" : "conv3x3_upc<32>");
                 if (bn == 64) {
                     static std::atomic<uint64_t> done64{0};
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<64>), done64));
@@ -1194,216 +1365,43 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             }
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
-            TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
-            launch_finalize(B, op.cout, st, e->d_part, ua.tiles_x * ua.tiles_y,
-                               op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+            TRY(finalize(Ht, Wt));
+            break;
+        }
+        case K_S1_RES32: case K_S1_RES32F: {
+            Tensor& dst = e->tensors[op.dst];
+            const int Ht = H >> op.ly, Wt = W >> op.lx;
+            Res32Args ra{};
+            ra.src = src.data; ra.sc = src.scale; ra.sh = src.shift; ra.wres = wts + op.dev_wres; ra.bias = wts + op.dev_b;
+            ra.oscale = wts + op.dev_ws; ra.dst = dst.data; ra.part = e->d_part;
+            ra.B = B; ra.H = Ht; ra.W = Wt; ra.tiles_x = g.tiles_x; ra.tiles_y = g.tiles_y; ra.n_tiles = g.n_mtiles;
+            ra.slope = a.leaky_slope;
+            ra.prof = prof;
+            // segment = the largest divisor of the tiles of one image that still leaves >= 2 workgroups per CU (or all tiles)
+            const int tpi_r = ra.tiles_x * ra.tiles_y, want = std::min(ra.n_tiles, 2 * e->num_cus);
+            int seg = 1;
+            for (int d = 1; d <= tpi_r; ++d) if (tpi_r % d == 0 && ra.n_tiles / d >= want) seg = d;
+            ra.seg = seg;
+            const int nbk = ra.n_tiles / seg;
+            const bool fuse0 = c.k == K_S1_RES32F;       // the first block was a statistics-only pass: recompute it here
+            if (fuse0) {
+                if (!e->fused_away[0]) return fail(TS2D_ERR_INVALID, "internal: fused second block without the statistics-only first pass");
+                const Op& o0 = e->ops[0];
+                ra.src = nullptr; ra.x0 = d_in; ra.C0 = o0.cin; ra.w0 = wts + o0.dev_wraw; ra.b0 = wts + o0.dev_b;
+            }
+            TRY(prof_begin(e, op.name, st)); prof_kernel(e, fuse0 ? "conv3x3_res32f" : "conv3x3_res32");
+#define TS2D_RES32(ST_, NP_, FUSE_, LDS_) do { static std::atomic<uint64_t> done_{0}; \
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_res32<ST_, NP_, FUSE_>), done_)); \
+                hipLaunchKernelGGL((conv3x3_res32<ST_, NP_, FUSE_>), dim3(nbk), dim3(kBlock), LDS_, st, ra); } while (0)
+            if (f16) { if (fuse0) TS2D_RES32(_Float16, 1, true, 9 * 4 * 512 + 4 * kResPS + 1536); else TS2D_RES32(_Float16, 1, false, 9 * 4 * 512 + 4 * kResPS + 1536); }
+            else { if (fuse0) TS2D_RES32(float, 3, true, 9 * 2 * 4 * 512 + 8 * kResPS); else TS2D_RES32(float, 3, false, 9 * 2 * 4 * 512 + 8 * kResPS); }
+#undef TS2D_RES32
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
-            continue;
+            TRY(finalize(Ht, Wt));
+            break;
         }
-        if (op.type == OP_CONV || op.type == OP_CONVT) {
-            const bool conv = op.type == OP_CONV;
-            Tensor& dst = e->tensors[op.dst];
-            const int Hin = H >> src.ly, Win = W >> src.lx;
-            const int Ht = conv ? (H >> op.ly) : Hin, Wt = conv ? (W >> op.lx) : Win;
-            const int taps = conv ? 9 : 1, stride = conv ? op.stride : 1;      // (the transposed conv tiles its INPUT pixels)
-            const bool aniso = conv ? op.stride == 3 : op.stride != 2;          // conv stride other than (1, 1) / (2, 2), transposed conv other than 2 x 2:
-                                                                                // the generic kernel, in every mode
-            const TileGeom g = tile_geom(B, Ht, Wt, conv ? op.sy : 1, conv ? op.sx : 1, taps);
-            ConvArgs ca{};
-            ca.ksplit = 1; ca.dbg = e->dbg;
-            ca.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
-            ca.src0 = src.data; ca.sc0 = src.scale; ca.sh0 = src.shift; ca.C0 = src.C;
-            if (op.skip >= 0) { const Tensor& sk = e->tensors[op.skip]; ca.src1 = sk.data; ca.sc1 = sk.scale; ca.sh1 = sk.shift; ca.C1 = sk.C; }
-            ca.wp = wts + op.dev_w; ca.bias = wts + op.dev_b; ca.dst = dst.data;
-            const bool fused = conv && g.lgNIMG == 0;
-            ca.part = fused ? e->d_part : nullptr;
-            ca.B = B; ca.Hin = Hin; ca.Win = Win; ca.Ht = Ht; ca.Wt = Wt;
-            ca.KA = conv ? 1 : op.sy; ca.KB = conv ? 1 : op.sx;
-            ca.N = conv ? op.cout : op.sy * op.sx * op.cout; ca.Cout = op.cout;
-            ca.lgTH = g.lgTH; ca.lgTW = g.lgTW; ca.lgNIMG = g.lgNIMG; ca.tiles_x = g.tiles_x; ca.tiles_y = g.tiles_y;
-            const int bn = (ca.N % 64 == 0 && op.cout % 64 == 0) ? 64 : 32;
-            ca.n_mtiles = g.n_mtiles; ca.n_ctiles = ca.N / bn; ca.PH = g.PH; ca.PW = g.PW; ca.slope = a.leaky_slope;
-            auto lg_exact = [](int v) { return (v > 0 && (v & (v - 1)) == 0) ? ilog2(v) : -1; };
-            ca.lg_tx = lg_exact(g.tiles_x); ca.lg_tpi = lg_exact(g.tiles_x * g.tiles_y); ca.lg_nct = lg_exact(ca.n_ctiles);
-            const int P = (g.PH * g.PW) << g.lgNIMG;
-            const bool split = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT;
-            if (f16 && !split && !aniso) return fail(TS2D_ERR_INVALID, "op %s has no fp16 kernel (channel counts must be multiples of 16)", op.name.c_str());
-            if (conv && split && op.s2v2_ok && e->use_s2v2 && e->use_one && stride == 2 && g.lgNIMG == 0 && Ht % 8 == 0 && Wt % 32 == 0 &&
-                ca.lg_tx >= 0 && ca.lg_tpi >= 0 && lg_exact(op.cout / op.bn2) >= 0 &&
-                (size_t)Hin * Win * op.cin * 4 < ((size_t)1 << 31) && (size_t)Ht * Wt * op.cout * 4 < ((size_t)1 << 31)) {
-                // stride-2 block on full 8 x 32 output tiles: one 512-thread workgroup per CU, up to 128 output columns
-                ca.n_ctiles = op.cout / op.bn2; ca.lg_nct = lg_exact(ca.n_ctiles);
-                ca.wph = wts + op.dev_w2; ca.oscale = wts + op.dev_ws; ca.part = e->d_part;
-                const int npp = f16 ? 1 : 2;
-                // persistent: one workgroup per CU walks its tiles; every chunk's weights resident in LDS when they fit beside the patch
-                const size_t wchunk = (size_t)9 * npp * 2 * op.bn2 * 16;
-                const bool resw = (size_t)npp * 2 * kS2Plane + (size_t)(op.cin / 16) * wchunk <= (size_t)160 * 1024;
-                const int grid2 = std::min((g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));
-                const size_t smem2 = (size_t)npp * 2 * kS2Plane + (resw ? (size_t)(op.cin / 16) : 1) * wchunk;
-                TRY(prof_begin(e, op.name, st)); prof_kernel(e, op.bn2 == 128 ? "conv3x3s2_v2<128>" : "conv3x3s2_v2<64>");
-#define TS2D_S2V2_LAUNCH(BN_, ST_, NP_) do { static std::atomic<uint64_t> done_{0}, doner_{0}; \
-                    if (resw) { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, true>), doner_)); \
-                                hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, true>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } \
-                    else { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, false>), done_)); \
-                           hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, false>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } } while (0)
-                if (op.bn2 == 128) { if (f16) TS2D_S2V2_LAUNCH(128, _Float16, 1); else TS2D_S2V2_LAUNCH(128, float, 3); }
-                else { if (f16) TS2D_S2V2_LAUNCH(64, _Float16, 1); else TS2D_S2V2_LAUNCH(64, float, 3); }
-#undef TS2D_S2V2_LAUNCH
-                HIP_TRY(hipGetLastError());
-                TRY(prof_end(e, st));
-                TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
-                launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
-                                   op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
-                HIP_TRY(hipGetLastError());
-                TRY(prof_end(e, st));
-                continue;
-            }
-            if (conv && split && op.res_ok && e->use_res && e->use_one && src.scale != nullptr && op.skip < 0 && Ht % 8 == 0 && Wt % 32 == 0 &&
-                (size_t)Ht * Wt * 32 * 4 < ((size_t)1 << 31)) {
-                // 32 -> 32 stride-1 block on full 8 x 32 tiles: persistent kernel with the layer's weights resident in LDS
-                Res32Args ra{};
-                ra.src = src.data; ra.sc = src.scale; ra.sh = src.shift; ra.wres = wts + op.dev_wres; ra.bias = wts + op.dev_b;
-                ra.oscale = wts + op.dev_ws; ra.dst = dst.data; ra.part = e->d_part;
-                ra.B = B; ra.H = Ht; ra.W = Wt; ra.tiles_x = Wt / 32; ra.tiles_y = Ht / 8; ra.n_tiles = B * ra.tiles_x * ra.tiles_y;
-                ra.slope = a.leaky_slope;
-                ra.prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
-                // segment = the largest divisor of the tiles of one image that still leaves >= 2 workgroups per CU (or all tiles)
-                const int tpi_r = ra.tiles_x * ra.tiles_y, want = std::min(ra.n_tiles, 2 * e->num_cus);
-                int seg = 1;
-                for (int d = 1; d <= tpi_r; ++d) if (tpi_r % d == 0 && ra.n_tiles / d >= want) seg = d;
-                ra.seg = seg;
-                const int nbk = ra.n_tiles / seg;
-                const bool fuse0 = oi == 1 && e->fused_away[0];       // the first block was a statistics-only pass: recompute it here
-                if (fuse0) {
-                    const Op& o0 = e->ops[0];
-                    ra.src = nullptr; ra.x0 = d_in; ra.C0 = o0.cin; ra.w0 = wts + o0.dev_wraw; ra.b0 = wts + o0.dev_b;
-                }
-                TRY(prof_begin(e, op.name, st)); prof_kernel(e, fuse0 ? "conv3x3_res32f" : "conv3x3_res32");
-#define TS2D_RES32(ST_, NP_, FUSE_, LDS_) do { static std::atomic<uint64_t> done_{0}; \
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_res32<ST_, NP_, FUSE_>), done_)); \
-                    hipLaunchKernelGGL((conv3x3_res32<ST_, NP_, FUSE_>), dim3(nbk), dim3(kBlock), LDS_, st, ra); } while (0)
-                if (f16) { if (fuse0) TS2D_RES32(_Float16, 1, true, 9 * 4 * 512 + 4 * kResPS + 1536); else TS2D_RES32(_Float16, 1, false, 9 * 4 * 512 + 4 * kResPS + 1536); }
-                else { if (fuse0) TS2D_RES32(float, 3, true, 9 * 2 * 4 * 512 + 8 * kResPS); else TS2D_RES32(float, 3, false, 9 * 2 * 4 * 512 + 8 * kResPS); }
-#undef TS2D_RES32
-                HIP_TRY(hipGetLastError());
-                TRY(prof_end(e, st));
-                TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
-                launch_finalize(B, op.cout, st, e->d_part, tpi_r,
-                                   op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
-                HIP_TRY(hipGetLastError());
-                TRY(prof_end(e, st));
-                continue;
-            }
-            if (split && !conv) {
-                ca.n_ctiles = ca.N / 64;                       // N = 4 * Cout is a multiple of 128; each 32-column tile lies in one (a,b) tap
-                ca.lg_nct = lg_exact(ca.n_ctiles);
-                ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
-                const int Pt = 1 << (g.lgTH + g.lgTW + g.lgNIMG);
-                const size_t smem_t = (size_t)2 * Pt * kRec + (size_t)2 * 64 * kRec;
-                const int grid_t = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
-                TRY(prof_begin(e, op.name, st)); prof_kernel(e, "convT2x2_f16x3");
-                const bool t_one = e->use_one && g.lgNIMG == 0 && (size_t)4 * Ht * Wt * op.cout * 4 < ((size_t)1 << 31) &&
-                                   ca.lg_tx >= 0 && ca.lg_tpi >= 0 && ca.lg_nct >= 0 && g.lgTH + g.lgTW == 8;
-                if (t_one) {
-                    if (f16) hipLaunchKernelGGL((convT2x2_f16x3_one<_Float16, 1>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
-                    else hipLaunchKernelGGL((convT2x2_f16x3_one<float, 3>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
-                } else if (f16) hipLaunchKernelGGL((convT2x2_f16x3<64, _Float16, 1>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
-                else hipLaunchKernelGGL((convT2x2_f16x3<64, float, 3>), dim3(grid_t), dim3(kBlock), smem_t, st, ca);
-                HIP_TRY(hipGetLastError());
-                TRY(prof_end(e, st));
-                continue;
-            }
-            size_t smem = std::max((size_t)(((P * (op.ck + 4) + 3) & ~3) + taps * (op.ck / 8) * bn * 8) * sizeof(float),
-                                   (size_t)4 * bn * 4 * sizeof(float));
-            if (split) {
-                smem = stride == 1 ? (size_t)P * kRec + (size_t)9 * bn * kRec : (size_t)P * kRec8 + (size_t)5 * bn * kRec;
-                smem = std::max(smem, (size_t)4 * bn * 4 * sizeof(float));
-                ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
-            }
-            const int ksplit = split ? choose_ksplit(e, op, B, H, W) : 1;
-            if (ksplit > 1) {
-                ca.ksplit = ksplit; ca.kslice_stride = (long long)B * Ht * Wt * op.cout;
-                ca.dst = e->d_partial; ca.part = nullptr;
-            }
-            if (smem > 160 * 1024) return fail(TS2D_ERR_INVALID, "op %s: LDS tile of %zu bytes exceeds 160 KiB", op.name.c_str(), smem);
-            const int grid = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
-            TRY(prof_begin(e, op.name, st));
-            hipError_t le;
-            // (both one-image kernels address a source image through a 32-bit buffer offset)
-            const bool img32 = (size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4 < ((size_t)1 << 31) && (size_t)Ht * Wt * op.cout * 4 < ((size_t)1 << 31) &&
-                               ca.lg_tx >= 0 && ca.lg_tpi >= 0 && ca.lg_nct >= 0 &&      // ... and decode power-of-two tilings with shifts
-                               g.lgTH + g.lgTW == 8;                                    // ... of complete 256-pixel tiles
-            const bool h32 = split && f16 && stride == 1 && op.h32_ok && e->use_h32 && g.lgNIMG == 0 && P * 4 <= 6 * kBlock && img32;
-            const bool one = split && !f16 && stride == 1 && e->use_one && g.lgNIMG == 0 && P * 2 <= 3 * kBlock && img32;
-            const bool one_s2 = split && stride == 2 && e->use_one && g.lgNIMG == 0 && P <= 5 * kBlock && img32;
-            const bool qtile = one && e->use_q && bn == 64 && ct_total(op) >= 64 && Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr &&      // (pays off from 4 chunks on: measured)
-                               (op.skip < 0 || e->tensors[op.skip].scale != nullptr) && lg_exact(Wt / 32) >= 0 && lg_exact((Wt / 32) * (Ht / 16)) >= 0;
-            const bool h2 = split && f16 && stride == 1 && e->use_h2 && op.cout % 64 == 0 && op.skip < 0 && ct_total(op) % 32 == 0 && g.lgNIMG == 0 && img32 &&
-                            Ht % 16 == 0 && Wt % 32 == 0 && src.scale != nullptr && lg_exact(Wt / 32) >= 0 && lg_exact((Wt / 32) * (Ht / 16)) >= 0 &&
-                            lg_exact(op.cout / 64) >= 0 && ct_total(op) >= e->h2_min;
-            if (h2) {
-                // 16-bit mode, plain C -> C block on 16 x 32 tiles: the skip phase of conv3x3_upc_h2 (four M tiles per wave, weights by LDS-DMA)
-                UpcArgs ua{};
-                ua.xs = src.data; ua.scs = src.scale; ua.shs = src.shift; ua.Cs = src.C;
-                ua.wk = wts + op.dev_wp; ua.bvar = wts + op.dev_b; ua.oscale = wts + op.dev_ws;
-                ua.dst = dst.data; ua.part = e->d_part;
-                ua.B = B; ua.H = Ht; ua.W = Wt; ua.Cout = op.cout;
-                ua.tiles_x = Wt / 32; ua.tiles_y = Ht / 16; ua.n_mtiles = B * ua.tiles_x * ua.tiles_y; ua.n_ctiles = op.cout / 64;
-                ua.lg_nct = ilog2(ua.n_ctiles); ua.lg_tx = ilog2(ua.tiles_x); ua.lg_tpi = ilog2(ua.tiles_x * ua.tiles_y);
-                ua.slope = a.leaky_slope; ua.dbg = e->dbg;
-                static std::atomic<uint64_t> doneh2p{0};
-                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h2<4, false>), doneh2p));
-                hipLaunchKernelGGL((conv3x3_upc_h2<4, false>), dim3((ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles), dim3(kBlock), kUh2Lds, st, ua);
-                le = hipGetLastError(); prof_kernel(e, "conv3x3_h2");
-                ca.tiles_x = ua.tiles_x; ca.tiles_y = ua.tiles_y;
-            } else if (qtile) {
-                // complete 16 x 32 tiles x 64 columns, normalised sources: one 512-thread workgroup per CU, patch and weights
-                // double-buffered (weights by LDS-DMA), one barrier per chunk
-                ca.wph = wts + op.dev_wp;
-                ca.tiles_x = Wt / 32; ca.tiles_y = Ht / 16; ca.n_mtiles = B * ca.tiles_x * ca.tiles_y;
-                ca.lg_tx = lg_exact(ca.tiles_x); ca.lg_tpi = lg_exact(ca.tiles_x * ca.tiles_y);
-                const int gridq = (ca.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
-                const int gridp = std::min(gridq, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));     // one persistent workgroup per CU
-                static std::atomic<uint64_t> doneqp{0};
-                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp), doneqp));
-                hipLaunchKernelGGL(conv3x3_f16x3_qp, dim3(gridp), dim3(kQThreads), kQpLds, st, ca);
-                le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp");
-            } else if (one) {     // tile inside one image: lean staging path
-                le = launch_one(bn, ca, grid, smem, st); prof_kernel(e, bn == 64 ? "conv3x3_f16x3_one<64>" : "conv3x3_f16x3_one<32>");
-            } else if (one_s2) {
-                le = launch_one_s2(f16, bn, ca, grid, smem, st); prof_kernel(e, "conv3x3s2_f16x3_one");
-            } else if (h32) {     // fp16 storage: 32-channel chunks, one product
-                ca.wph = wts + op.dev_wh32;
-                le = launch_h32(bn, ca, grid, smem, st); prof_kernel(e, bn == 64 ? "conv3x3_h32<64>" : "conv3x3_h32<32>");
-            } else if (split) {
-                le = stride == 1 ? launch_split(f16, bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, grid, smem, st)
-                                 : launch_split_s2(f16, bn, P <= 5 * kBlock ? 5 : 6, ca, grid, smem, st);
-                prof_kernel(e, stride == 1 ? "conv3x3_f16x3" : "conv3x3s2_f16x3");
-            } else {
-                le = launch_conv(taps, conv ? op.sy : 1, conv ? op.sx : 1, op.ck, bn, f16 && aniso, ca, grid, smem, st);
-                prof_kernel(e, conv ? "conv_mfma_f32" : "convT_mfma_f32");
-            }
-            if (le != hipSuccess) return fail(TS2D_ERR_HIP, "launch of %s failed: %s", op.name.c_str(), hipGetErrorString(le));
-            TRY(prof_end(e, st));
-            if (conv) {
-                const int HW = Ht * Wt;
-                TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
-                if (ksplit > 1) {
-                    if (f16) hipLaunchKernelGGL(splitk_reduce_stats<_Float16>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, ksplit, ca.kslice_stride,
-                                                wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, reinterpret_cast<_Float16*>(dst.data), dst.scale, dst.shift);
-                    else hipLaunchKernelGGL(splitk_reduce_stats<float>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, ksplit, ca.kslice_stride,
-                                            wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.data, dst.scale, dst.shift);
-                } else if (fused) {
-                    launch_finalize(B, op.cout, st, e->d_part, (qtile || h2) ? ca.tiles_x * ca.tiles_y : g.tiles_x * g.tiles_y,
-                                       op.cout, B, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
-                } else {
-                    launch_stats_direct(f16, B, op.cout, HW, dst.data, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift, st);
-                }
-                HIP_TRY(hipGetLastError());
-                TRY(prof_end(e, st));
-            }
-        } else {
+        case K_HEAD_MFMA: case K_HEAD_1X1: {
             HeadArgs ha{};
             ha.src = src.data; ha.sc = src.scale; ha.sh = src.shift; ha.w = wts + op.dev_w; ha.bias = wts + op.dev_b;
             ha.logits = d_logits; ha.mask = d_mask; ha.C = src.C; ha.K = op.cout; ha.HW = H * W;
@@ -1412,8 +1410,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             const size_t smem = ((size_t)256 * (src.C + 1) + (size_t)op.cout * src.C + op.cout) * sizeof(float);
             TRY(prof_begin(e, op.name, st));
             prof_kernel(e, "head");
-            const bool hm = op.split_ok && e->precision != TS2D_PRECISION_F32_EXACT && e->use_one && src.C == 32 && (H * W) % 32 == 0 && W % 32 == 0;
-            if (hm) {      // matrix-core head (split / f16 modes)
+            if (c.k == K_HEAD_MFMA) {      // matrix-core head (split / f16 modes)
                 ha.wph = wts + op.dev_wh; ha.oscale = wts + op.dev_ws;
                 const int bpw = 16;
                 const long long nblk = ha.total / 32;
@@ -1435,10 +1432,150 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             }
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
+            break;
+        }
+        default: {      // every kernel that takes ConvArgs
+            const bool conv = op.type == OP_CONV;
+            Tensor& dst = e->tensors[op.dst];
+            const int Hin = H >> src.ly, Win = W >> src.lx;
+            const int Ht = conv ? (H >> op.ly) : Hin, Wt = conv ? (W >> op.lx) : Win;
+            const int taps = conv ? 9 : 1, bn = c.bn;
+            ConvArgs ca{};
+            ca.ksplit = 1; ca.dbg = e->dbg; ca.prof = prof;
+            ca.src0 = src.data; ca.sc0 = src.scale; ca.sh0 = src.shift; ca.C0 = src.C;
+            if (op.skip >= 0) { const Tensor& sk = e->tensors[op.skip]; ca.src1 = sk.data; ca.sc1 = sk.scale; ca.sh1 = sk.shift; ca.C1 = sk.C; }
+            ca.wp = wts + op.dev_w; ca.bias = wts + op.dev_b; ca.dst = dst.data;
+            ca.part = (conv && c.fused_stats) ? e->d_part : nullptr;
+            ca.B = B; ca.Hin = Hin; ca.Win = Win; ca.Ht = Ht; ca.Wt = Wt;
+            ca.KA = conv ? 1 : op.sy; ca.KB = conv ? 1 : op.sx;
+            ca.N = conv ? op.cout : op.sy * op.sx * op.cout; ca.Cout = op.cout;
+            set_tiling(ca, g, ca.N / bn);
+            ca.slope = a.leaky_slope;
+            const int P = g.PH * g.PW * g.NIMG;
+            const int grid = (g.n_mtiles + 7) / 8 * 8 * ca.n_ctiles;
+            hipError_t le = hipSuccess;
+            TRY(prof_begin(e, op.name, st));
+            switch (c.k) {
+            case K_S2_V2: {
+                ca.wph = wts + op.dev_w2; ca.oscale = wts + op.dev_ws;
+                const int npp = f16 ? 1 : 2;
+                // persistent: one workgroup per CU walks its tiles; every chunk's weights resident in LDS when they fit beside the patch
+                const size_t wchunk = (size_t)9 * npp * 2 * op.bn2 * 16;
+                const bool resw = (size_t)npp * 2 * kS2Plane + (size_t)(op.cin / 16) * wchunk <= (size_t)160 * 1024;
+                const int grid2 = std::min(grid, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));
+                const size_t smem2 = (size_t)npp * 2 * kS2Plane + (resw ? (size_t)(op.cin / 16) : 1) * wchunk;
+                prof_kernel(e, op.bn2 == 128 ? "conv3x3s2_v2<128>" : "conv3x3s2_v2<64>");
+#define TS2D_S2V2_LAUNCH(BN_, ST_, NP_) do { static std::atomic<uint64_t> done_{0}, doner_{0}; \
+                    if (resw) { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, true>), doner_)); \
+                                hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, true>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } \
+                    else { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, false>), done_)); \
+                           hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, false>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } } while (0)
+                if (op.bn2 == 128) { if (f16) TS2D_S2V2_LAUNCH(128, _Float16, 1); else TS2D_S2V2_LAUNCH(128, float, 3); }
+                else { if (f16) TS2D_S2V2_LAUNCH(64, _Float16, 1); else TS2D_S2V2_LAUNCH(64, float, 3); }
+#undef TS2D_S2V2_LAUNCH
+                le = hipGetLastError();
+                break;
+            }
+            case K_T_ONE: case K_T_GENERIC: {
+                ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
+                const int Pt = g.TH * g.TW * g.NIMG;
+                const size_t smem_t = (size_t)2 * Pt * kRec + (size_t)2 * 64 * kRec;
+                prof_kernel(e, "convT2x2_f16x3");
+                if (c.k == K_T_ONE) {
+                    if (f16) hipLaunchKernelGGL((convT2x2_f16x3_one<_Float16, 1>), dim3(grid), dim3(kBlock), smem_t, st, ca);
+                    else hipLaunchKernelGGL((convT2x2_f16x3_one<float, 3>), dim3(grid), dim3(kBlock), smem_t, st, ca);
+                } else if (f16) hipLaunchKernelGGL((convT2x2_f16x3<64, _Float16, 1>), dim3(grid), dim3(kBlock), smem_t, st, ca);
+                else hipLaunchKernelGGL((convT2x2_f16x3<64, float, 3>), dim3(grid), dim3(kBlock), smem_t, st, ca);
+                le = hipGetLastError();
+                break;
+            }
+            case K_S1_H2: {
+                // 16-bit mode, plain C -> C block on 16 x 32 tiles: the skip phase of conv3x3_upc_h2 (four M tiles per wave, weights by LDS-DMA)
+                UpcArgs ua{};
+                ua.xs = src.data; ua.scs = src.scale; ua.shs = src.shift; ua.Cs = src.C;
+                ua.wk = wts + op.dev_wp; ua.bvar = wts + op.dev_b; ua.oscale = wts + op.dev_ws;
+                ua.dst = dst.data; ua.part = e->d_part;
+                ua.B = B; ua.H = Ht; ua.W = Wt; ua.Cout = op.cout;
+                ua.tiles_x = g.tiles_x; ua.tiles_y = g.tiles_y; ua.n_mtiles = g.n_mtiles; ua.n_ctiles = op.cout / 64;
+                ua.slope = a.leaky_slope; ua.dbg = e->dbg;
+                static std::atomic<uint64_t> doneh2p{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h2<4, false>), doneh2p));
+                hipLaunchKernelGGL((conv3x3_upc_h2<4, false>), dim3((ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles), dim3(kBlock), kUh2Lds, st, ua);
+                le = hipGetLastError(); prof_kernel(e, "conv3x3_h2");
+                break;
+            }
+            case K_S1_QP: {
+                // complete 16 x 32 tiles x 64 columns, normalised sources: one 512-thread workgroup per CU, patch and weights
+                // double-buffered (weights by LDS-DMA), one barrier per chunk
+                ca.wph = wts + op.dev_wp; ca.oscale = wts + op.dev_ws;
+                const int gridp = std::min(grid, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));     // one persistent workgroup per CU
+                static std::atomic<uint64_t> doneqp{0};
+                HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_f16x3_qp), doneqp));
+                hipLaunchKernelGGL(conv3x3_f16x3_qp, dim3(gridp), dim3(kQThreads), kQpLds, st, ca);
+                le = hipGetLastError(); prof_kernel(e, "conv3x3_f16x3_qp");
+                break;
+            }
+            default: {
+                const bool s2 = op.stride == 2;
+                size_t smem = std::max((size_t)(((P * (op.ck + 4) + 3) & ~3) + taps * (op.ck / 8) * bn * 8) * sizeof(float),
+                                       (size_t)4 * bn * 4 * sizeof(float));
+                if (c.k != K_EXACT) {
+                    smem = !s2 ? (size_t)P * kRec + (size_t)9 * bn * kRec : (size_t)P * kRec8 + (size_t)5 * bn * kRec;
+                    smem = std::max(smem, (size_t)4 * bn * 4 * sizeof(float));
+                    ca.wph = wts + op.dev_wh; ca.oscale = wts + op.dev_ws;
+                }
+                if (c.ksplit > 1) {
+                    ca.ksplit = c.ksplit; ca.kslice_stride = (long long)B * Ht * Wt * op.cout;
+                    ca.dst = e->d_partial; ca.part = nullptr;
+                }
+                if (smem > 160 * 1024) return fail(TS2D_ERR_INVALID, "op %s: LDS tile of %zu bytes exceeds 160 KiB", op.name.c_str(), smem);
+                if (c.k == K_S1_ONE) {     // tile inside one image: lean staging path
+                    le = launch_one(bn, ca, grid, smem, st); prof_kernel(e, bn == 64 ? "conv3x3_f16x3_one<64>" : "conv3x3_f16x3_one<32>");
+                } else if (c.k == K_S2_ONE) {
+                    le = launch_one_s2(f16, bn, ca, grid, smem, st); prof_kernel(e, "conv3x3s2_f16x3_one");
+                } else if (c.k == K_S1_H32) {     // fp16 storage: 32-channel chunks, one product
+                    ca.wph = wts + op.dev_wh32;
+                    le = launch_h32(bn, ca, grid, smem, st); prof_kernel(e, bn == 64 ? "conv3x3_h32<64>" : "conv3x3_h32<32>");
+                } else if (c.k == K_S1_GENERIC) {
+                    le = launch_split(f16, bn, P * 2 <= 3 * kBlock ? 3 : 5, ca, grid, smem, st); prof_kernel(e, "conv3x3_f16x3");
+                } else if (c.k == K_S2_GENERIC) {
+                    le = launch_split_s2(f16, bn, P <= 5 * kBlock ? 5 : 6, ca, grid, smem, st); prof_kernel(e, "conv3x3s2_f16x3");
+                } else {      // K_EXACT: the whole exact mode; in every mode the stages whose stride is neither (1, 1) nor (2, 2)
+                    const bool aniso = conv ? op.stride == 3 : op.stride != 2;
+                    le = launch_conv(taps, conv ? op.sy : 1, conv ? op.sx : 1, op.ck, bn, f16 && aniso, ca, grid, smem, st);
+                    prof_kernel(e, conv ? "conv_mfma_f32" : "convT_mfma_f32");
+                }
+                break;
+            }
+            }
+            if (le != hipSuccess) return fail(TS2D_ERR_HIP, "launch of %s failed: %s", op.name.c_str(), hipGetErrorString(le));
+            TRY(prof_end(e, st));
+            if (conv) {
+                const int HW = Ht * Wt;
+                if (c.ksplit > 1) {
+                    TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
+                    if (f16) hipLaunchKernelGGL(splitk_reduce_stats<_Float16>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, c.ksplit, ca.kslice_stride,
+                                                wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, reinterpret_cast<_Float16*>(dst.data), dst.scale, dst.shift);
+                    else hipLaunchKernelGGL(splitk_reduce_stats<float>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, c.ksplit, ca.kslice_stride,
+                                            wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.data, dst.scale, dst.shift);
+                    HIP_TRY(hipGetLastError());
+                    TRY(prof_end(e, st));
+                } else if (c.fused_stats) {
+                    TRY(finalize(Ht, Wt));
+                } else {
+                    TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
+                    launch_stats_direct(f16, B, op.cout, HW, dst.data, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift, st);
+                    HIP_TRY(hipGetLastError());
+                    TRY(prof_end(e, st));
+                }
+            }
+            break;
+        }
         }
     }
     return TS2D_OK;
 }
+
 
 }  // namespace
 

@@ -71,6 +71,10 @@ __device__ __forceinline__ void stat_tile_store(const float* red, int nwaves, in
 constexpr int kBlock = 256;   // threads per workgroup (4 waves, one per SIMD)
 constexpr int kBM = 256;      // output pixels per workgroup tile
 
+// n / d for 0 <= n < 2^22 by the float reciprocal inv_d = 1.0f / d (correctly rounded, computed on the host): exact, because
+// (n + 0.5) / d is at least 0.5 / d away from an integer and the two roundings move it by less than (n + 0.5) 2^-23 / d.
+__device__ __forceinline__ int fdiv(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
+
 // ------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain).
 //   GEMM view: M = output pixels, N = output channels, K = TAPS * Cin.
@@ -91,11 +95,14 @@ struct ConvArgs {
     int Ht, Wt;           // tile-space dims (= output dims for conv, = input dims for convT)
     int N;                // GEMM N (= Cout for conv, 4*Cout for convT)
     int Cout;             // real output channels (dst channel stride)
-    int lgTH, lgTW, lgNIMG;
+    int TH, TW, NIMG;     // pixel tile = NIMG images x TH x TW pixels (NIMG * TH * TW <= 256; any extents - round 5: a level of 80 x 48 or
+                          // 28 x 36 pixels gets tiles that divide it, e.g. 5 x 48 or 7 x 36, instead of idle rows in power-of-two tiles)
+    float inv_tw, inv_thw;       // 1 / TW, 1 / (TH * TW) for tile_row()
+    int lgTH, lgTW;       // log2 of TH / TW when BOTH are powers of two, else -1 (the fast epilogues address a tile row with shifts)
     int tiles_x, tiles_y; // tiles per image
     int n_mtiles, n_ctiles;
-    int lg_nct, lg_tx, lg_tpi;   // log2 of n_ctiles / tiles_x / tiles_x*tiles_y when a power of two, else -1 (the one-image kernels
-                                 // decode their block index with shifts and are only launched when all three are >= 0)
+    float inv_tx, inv_tpi, inv_nct;      // 1 / tiles_x, 1 / (tiles_x * tiles_y), 1 / n_ctiles: the persistent kernels decode a tile number per item
+                                         // with fdiv() (any tile count: the power-of-two gate of rounds 1-4 is gone)
     int PH, PW;           // staged patch dims per image
     int KA, KB;           // transposed conv (conv_mfma_f32, TAPS == 1): kernel = stride (along H, along W); N = KA * KB * Cout
     float slope;
@@ -108,6 +115,13 @@ struct ConvArgs {
     const float* oscale;  // device scalar: 1 / (power-of-two weight pre-scale); lives in the weight arena so that it
                           // travels with the multi-GPU weight broadcast (f16x3 kernel only)
 };
+
+// row m of a pixel tile -> (image inside the tile, y, x inside the image's TH x TW part); rows past NIMG * TH * TW give il >= NIMG
+__device__ __forceinline__ void tile_row(const ConvArgs& a, int m, int& il, int& ty, int& tx) {
+    il = fdiv(m, a.inv_thw);
+    const int rem = m - il * (a.TH * a.TW);
+    ty = fdiv(rem, a.inv_tw); tx = rem - ty * a.TW;
+}
 
 template <int SY, int SX, int CK>
 struct ConvCfg {
@@ -149,18 +163,18 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
     if (mtile >= a.n_mtiles) return;                       // uniform: whole workgroup leaves before any barrier
     const int n0col = ctile * BN;
 
-    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW, NIMG = 1 << a.lgNIMG;
+    const int NIMG = a.NIMG;
     const int tpi = a.tiles_x * a.tiles_y;
     const int grp = mtile / tpi, tin = mtile - grp * tpi;
     const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
-    const int nimg0 = grp << a.lgNIMG;
-    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+    const int nimg0 = grp * NIMG;
+    const int ty0 = tyi * a.TH, tx0 = txi * a.TW;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
     const int PHW = a.PH * a.PW;
-    const int P = PHW << a.lgNIMG;
+    const int P = PHW * NIMG;
     float* sA = smem;
     float* sB = smem + ((P * PSTR + 3) & ~3);
 
@@ -189,7 +203,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = 64 * w + 32 * mt + r;
-        const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+        int il, ty, tx;
+        tile_row(a, m, il, ty, tx);
         // rows past the tile's NIMG*TH*TW pixels (tiny images: NIMG is capped at 16) read a valid dummy address
         abase[mt] = (il < NIMG ? (il * PHW + ty * SY * a.PW + tx * SX) * PSTR : 0) + 4 * h;
     }
@@ -222,14 +237,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
             }
             if (sc != nullptr) {
                 f32x4 s1 = f32x4{1.f, 1.f, 1.f, 1.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (a.lgNIMG == 0 && nimg0 < a.B) {
+                if (NIMG == 1 && nimg0 < a.B) {
                     s1 = *reinterpret_cast<const f32x4*>(sc + (size_t)nimg0 * C + coff);
                     s2 = *reinterpret_cast<const f32x4*>(sh + (size_t)nimg0 * C + coff);
                 }
 #pragma unroll
                 for (int it = 0; it < MAXIT; ++it) {
                     if (goff[it] >= 0) {
-                        if (a.lgNIMG != 0) {
+                        if (NIMG != 1) {
                             const int n = nimg0 + (int)((imgbits >> (4 * it)) & 15);
                             s1 = *reinterpret_cast<const f32x4*>(sc + (size_t)n * C + coff);
                             s2 = *reinterpret_cast<const f32x4*>(sh + (size_t)n * C + coff);
@@ -325,7 +340,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_f32(const ConvArgs a) {
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
                 const int m = 64 * w + 32 * mt + row;
-                const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+                int il, ty, tx;
+                tile_row(a, m, il, ty, tx);
                 const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
                 if (il < NIMG && n < a.B && oy < a.Ht && ox < a.Wt) {
                     const float v = acc_t[mt][nt][i] + bv;

@@ -92,7 +92,7 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
                                                int n0col, int nimg0, int ty0, int tx0, int tpi, int tin) {
     constexpr int NT = BN / 32;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW, NIMG = 1 << a.lgNIMG;
+    const int NIMG = a.NIMG;
     const float oscale = *a.oscale;
     float st_s[NT], st_q[NT], st_k[NT], st_n[NT];
 #pragma unroll
@@ -109,7 +109,8 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
                 const int m = 64 * w + 32 * mt + row;
-                const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+                int il, ty, tx;
+                tile_row(a, m, il, ty, tx);
                 const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
                 if (il < NIMG && n < a.B && oy < a.Ht && ox < a.Wt) {
                     float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);      // explicit FMAs: the same rounding in every instantiation
@@ -154,8 +155,9 @@ template <int BN, typename ST = float>
 __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&acc_t)[2][BN / 32], unsigned char* smem8,
                                                    int n0col, int nimg0, int ty0, int tx0, int tpi, int tin) {
     constexpr int NT = BN / 32;
-    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW;
-    const bool full = a.ksplit == 1 && a.lgTH + a.lgTW == 8 && ty0 + TH <= a.Ht && tx0 + TW <= a.Wt && a.lgTW >= 4 && nimg0 < a.B;     // wave-uniform
+    const int TH = a.TH, TW = a.TW;
+    const bool full = a.ksplit == 1 && a.lgTW >= 4 && a.lgTH + a.lgTW == 8 && ty0 + TH <= a.Ht && tx0 + TW <= a.Wt && nimg0 < a.B;     // wave-uniform
+    // (power-of-two tiles of 256 pixels only: lgTW = -1 for the tile shapes of ragged levels, which take the general epilogue)
     if (!full) { split_epilogue<BN, ST>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const float oscale = *a.oscale;
@@ -215,18 +217,18 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
     if (mtile >= a.n_mtiles) return;
     const int n0col = ctile * BN;
 
-    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW, NIMG = 1 << a.lgNIMG;
+    const int NIMG = a.NIMG;
     const int tpi = a.tiles_x * a.tiles_y;
     const int grp = mtile / tpi, tin = mtile - grp * tpi;
     const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
-    const int nimg0 = grp << a.lgNIMG;
-    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+    const int nimg0 = grp * NIMG;
+    const int ty0 = tyi * a.TH, tx0 = txi * a.TW;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
     const int PHW = a.PH * a.PW;
-    const int P = PHW << a.lgNIMG;
+    const int P = PHW * NIMG;
     unsigned char* sA = smem8;
     unsigned char* sB = smem8 + P * kRec;
 
@@ -255,7 +257,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = 64 * w + 32 * mt + r;
-        const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+        int il, ty, tx;
+        tile_row(a, m, il, ty, tx);
         abase[mt] = (il < NIMG ? (il * PHW + ty * a.PW + tx) * kRec : 0) + 16 * h;
     }
     const int bbase = r * kRec + 16 * h;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
         // ---- patch: normalise + LeakyReLU, split into fp16 hi/lo, write the LDS records
         {
             f32x4 s1a = f32x4{1.f, 1.f, 1.f, 1.f}, s1b = s1a, s2a = f32x4{0.f, 0.f, 0.f, 0.f}, s2b = s2a;
-            if (sc != nullptr && a.lgNIMG == 0 && nimg0 < a.B) {
+            if (sc != nullptr && NIMG == 1 && nimg0 < a.B) {
                 const size_t o = (size_t)nimg0 * C + cb + oct;
                 s1a = *reinterpret_cast<const f32x4*>(sc + o); s1b = *reinterpret_cast<const f32x4*>(sc + o + 4);
                 s2a = *reinterpret_cast<const f32x4*>(sh + o); s2b = *reinterpret_cast<const f32x4*>(sh + o + 4);
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_f16x3(const ConvArgs a) {
                     f32x4 va, vb;
                     pv[s][it].get(va, vb);
                     if (sc != nullptr && goff[it] >= 0) {
-                        if (a.lgNIMG != 0) {
+                        if (NIMG != 1) {
                             const size_t o = (size_t)(nimg0 + (int)((imgbits >> (4 * it)) & 15)) * C + cb + oct;
                             s1a = *reinterpret_cast<const f32x4*>(sc + o); s1b = *reinterpret_cast<const f32x4*>(sc + o + 4);
                             s2a = *reinterpret_cast<const f32x4*>(sh + o); s2b = *reinterpret_cast<const f32x4*>(sh + o + 4);
@@ -472,18 +475,18 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
     if (mtile >= a.n_mtiles) return;
     const int n0col = ctile * BN;
 
-    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW, NIMG = 1 << a.lgNIMG;
+    const int NIMG = a.NIMG;
     const int tpi = a.tiles_x * a.tiles_y;
     const int grp = mtile / tpi, tin = mtile - grp * tpi;
     const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
-    const int nimg0 = grp << a.lgNIMG;
-    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+    const int nimg0 = grp * NIMG;
+    const int ty0 = tyi * a.TH, tx0 = txi * a.TW;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
     const int PHW = a.PH * a.PW, PWe = (a.PW + 1) >> 1;
-    const int P = PHW << a.lgNIMG;
+    const int P = PHW * NIMG;
     unsigned char* sA = smem8;
     unsigned char* sB = smem8 + P * kRec8;
 
@@ -509,7 +512,8 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = 64 * w + 32 * mt + r;
-        const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+        int il, ty, tx;
+        tile_row(a, m, il, ty, tx);
         abase[mt] = (il < NIMG ? (il * PHW + 2 * ty * a.PW + tx) * kRec8 : 0);
     }
     int tofl[5];      // this lane half's tap offset per k-step (tap 9 does not exist: reuse tap 8, its weights are 0)
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
         __syncthreads();
         {
             f32x4 s1a = f32x4{1.f, 1.f, 1.f, 1.f}, s1b = s1a, s2a = f32x4{0.f, 0.f, 0.f, 0.f}, s2b = s2a;
-            if (a.sc0 != nullptr && a.lgNIMG == 0 && nimg0 < a.B) {
+            if (a.sc0 != nullptr && NIMG == 1 && nimg0 < a.B) {
                 const size_t o = (size_t)nimg0 * a.C0 + cb;
                 s1a = *reinterpret_cast<const f32x4*>(a.sc0 + o); s1b = *reinterpret_cast<const f32x4*>(a.sc0 + o + 4);
                 s2a = *reinterpret_cast<const f32x4*>(a.sh0 + o); s2b = *reinterpret_cast<const f32x4*>(a.sh0 + o + 4);
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3s2_f16x3(const ConvArgs a) {
                     f32x4 va, vb;
                     pv[it].get(va, vb);
                     if (a.sc0 != nullptr && goff[it] >= 0) {
-                        if (a.lgNIMG != 0) {
+                        if (NIMG != 1) {
                             const size_t o = (size_t)(nimg0 + (int)((imgbits >> (4 * it)) & 15)) * a.C0 + cb;
                             s1a = *reinterpret_cast<const f32x4*>(a.sc0 + o); s1b = *reinterpret_cast<const f32x4*>(a.sc0 + o + 4);
                             s2a = *reinterpret_cast<const f32x4*>(a.sh0 + o); s2b = *reinterpret_cast<const f32x4*>(a.sh0 + o + 4);

@@ -21,17 +21,17 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
     if (mtile >= a.n_mtiles) return;
     const int n0col = ctile * BN;
 
-    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW, NIMG = 1 << a.lgNIMG;
+    const int NIMG = a.NIMG;
     const int tpi = a.tiles_x * a.tiles_y;
     const int grp = mtile / tpi, tin = mtile - grp * tpi;
     const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
-    const int nimg0 = grp << a.lgNIMG;
-    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+    const int nimg0 = grp * NIMG;
+    const int ty0 = tyi * a.TH, tx0 = txi * a.TW;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    const int P = (TH * TW) << a.lgNIMG;              // <= 256 tile pixels, no halo
+    const int P = a.TH * a.TW * NIMG;                 // <= 256 tile pixels, no halo
     unsigned char* sA = smem8;                        // [kk 2][P][80 B]
     unsigned char* sB = smem8 + 2 * P * kRec;         // [kk 2][BN][80 B]
 
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
         const int m = u >> 2;
         int g = -1, n = 0;
         if (m < P) {
-            const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+            int il, ty, tx;
+            tile_row(a, m, il, ty, tx);
             n = nimg0 + il;
             const int iy = ty0 + ty, ix = tx0 + tx;
             if (il < NIMG && n < a.B && iy < a.Hin && ix < a.Win) g = (n * a.Hin + iy) * a.Win + ix;
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3(const ConvArgs a) {
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
                 const int m = 64 * w + 32 * mt + row;
-                const int il = m >> (a.lgTH + a.lgTW), ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
+                int il, ty, tx;
+                tile_row(a, m, il, ty, tx);
                 const int n = nimg0 + il, oy = ty0 + ty, ox = tx0 + tx;
                 if (il < NIMG && n < a.B && oy < a.Ht && ox < a.Wt)
                     store_act<ST>(a.dst, ((size_t)(n * 2 * a.Ht + 2 * oy + oa) * (2 * a.Wt) + 2 * ox + ob) * a.Cout + co,
@@ -189,22 +191,22 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3_one(const ConvArgs a
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = bid >> 3;
-    const int qm = q8 >> a.lg_nct;                  // (one-image kernels: power-of-two tilings only, the engine checks)
+    const int qm = q8 / a.n_ctiles;                 // (any tile count, any tile shape: round 5)
     const int mtile = qm * 8 + xcd;
     const int ctile = q8 - qm * a.n_ctiles;
     if (mtile >= a.n_mtiles) return;
     const int n0col = ctile * BN;
 
-    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW;
+    const int TH = a.TH, TW = a.TW;
     const int tpi = a.tiles_x * a.tiles_y;
-    const int nimg0 = mtile >> a.lg_tpi, tin = mtile - nimg0 * tpi;
-    const int tyi = tin >> a.lg_tx, txi = tin - tyi * a.tiles_x;
-    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+    const int nimg0 = mtile / tpi, tin = mtile - nimg0 * tpi;
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    const int P = TH * TW;                            // 256 tile pixels, no halo
+    const int P = TH * TW;                            // <= 256 tile pixels, no halo
     unsigned char* sA = smem8;                        // [kk 2][P][80 B]
     unsigned char* sB = smem8 + 2 * P * kRec;         // [kk 2][BN][80 B]
 
@@ -215,11 +217,13 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3_one(const ConvArgs a
 #pragma unroll
     for (int it = 0; it < MAXU; ++it) {
         const int u = tid + it * kBlock, m = u >> 2;
-        const int iy = ty0 + (m >> a.lgTW), ix = tx0 + (m & (TW - 1));
-        const bool in = iy < a.Hin && ix < a.Win;
+        int il, tyy, txx;
+        tile_row(a, m, il, tyy, txx);
+        const int iy = ty0 + tyy, ix = tx0 + txx;
+        const bool in = il == 0 && iy < a.Hin && ix < a.Win;
         vo[it] = in ? (unsigned)(((iy * a.Win + ix) * a.C0 + oct) * (int)sizeof(ST)) : 0x80000000u;
         inside |= (in ? 1u : 0u) << it;
-        if (!in) {                                    // never staged: zero once
+        if (!in && m < P) {                           // never staged: zero once
             unsigned char* d = sA + (((u & 3) >> 1) * P + m) * kRec + (u & 1) * 16;
             *reinterpret_cast<uint4*>(d) = uint4{0u, 0u, 0u, 0u};
             if (NP == 3) *reinterpret_cast<uint4*>(d + 32) = uint4{0u, 0u, 0u, 0u};
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3_one(const ConvArgs a
     }
 
     const float oscale = *a.oscale;
-    const bool full = a.lgTH + a.lgTW == 8 && ty0 + TH <= a.Ht && tx0 + TW <= a.Wt && a.lgTW >= 4;     // wave-uniform
+    const bool full = a.lgTW >= 4 && a.lgTH + a.lgTW == 8 && ty0 + TH <= a.Ht && tx0 + TW <= a.Wt;     // wave-uniform (power-of-two tiles only)
     const size_t out_el = (size_t)4 * a.Ht * a.Wt * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * out_el, 0, (int)(out_el * sizeof(ST)), 0x00020000);
 #pragma unroll
@@ -362,8 +366,10 @@ __global__ __launch_bounds__(kBlock, 2) void convT2x2_f16x3_one(const ConvArgs a
                 for (int i = 0; i < 16; ++i) {
                     const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
                     const int m = 64 * w + 32 * mt + row;
-                    const int oy = ty0 + (m >> a.lgTW), ox = tx0 + (m & (TW - 1));
-                    if (oy < a.Ht && ox < a.Wt)
+                    int il, tyy, txx;
+                    tile_row(a, m, il, tyy, txx);
+                    const int oy = ty0 + tyy, ox = tx0 + txx;
+                    if (il == 0 && oy < a.Ht && ox < a.Wt)
                         store_act<ST>(a.dst, ((size_t)(nimg0 * 2 * a.Ht + 2 * oy + oa) * (2 * a.Wt) + 2 * ox + ob) * a.Cout + co,
                                       acc[mt][nt][i] * oscale + bv);
                 }

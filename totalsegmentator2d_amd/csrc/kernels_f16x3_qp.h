@@ -52,8 +52,9 @@ __global__ TS2D_PACKED_F32 __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp
 
     // ---- this workgroup's tiles: virtual block v = blockIdx.x + k * gridDim.x -> (xcd, column tile) fixed, pixel tile mtile0 + k * mstep
     const int xcd = blockIdx.x & 7, q80 = blockIdx.x >> 3;
-    const int ctile = q80 & (a.n_ctiles - 1), n0col = ctile * BN;
-    const int mtile0 = (q80 >> a.lg_nct) * 8 + xcd, mstep = ((int)(gridDim.x >> 3) >> a.lg_nct) * 8;
+    const int qm0 = q80 / a.n_ctiles;                       // (any tile count: round 5; the grid is a multiple of 8 * n_ctiles)
+    const int ctile = q80 - qm0 * a.n_ctiles, n0col = ctile * BN;
+    const int mtile0 = qm0 * 8 + xcd, mstep = ((int)(gridDim.x >> 3) / a.n_ctiles) * 8;
     if (mtile0 >= a.n_mtiles) return;
     const int ntl = (a.n_mtiles - 1 - mtile0) / mstep + 1;                 // tiles of this workgroup
     const int nchunks = (a.C0 + a.C1) / 16;
@@ -85,8 +86,8 @@ __global__ TS2D_PACKED_F32 __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp
     };
     auto tile_origin = [&](int k, int& nimg, int& ty0, int& tx0, int& tin) {
         const int mtile = mtile0 + k * mstep;
-        nimg = mtile >> a.lg_tpi; tin = mtile - nimg * tpi;
-        const int tyi = tin >> a.lg_tx, txi = tin - tyi * a.tiles_x;
+        nimg = fdiv(mtile, a.inv_tpi); tin = mtile - nimg * tpi;
+        const int tyi = fdiv(tin, a.inv_tx), txi = tin - tyi * a.tiles_x;
         ty0 = tyi << 4; tx0 = txi << 5;
     };
 

@@ -49,17 +49,16 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_h32(const ConvArgs a) {
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = bid >> 3;
-    const int qm = q8 >> a.lg_nct;                  // (one-image kernels: power-of-two tilings only, the engine checks)
+    const int qm = q8 / a.n_ctiles;                 // (any tile count, any tile shape: round 5)
     const int mtile = qm * 8 + xcd;
     const int ctile = q8 - qm * a.n_ctiles;
     if (mtile >= a.n_mtiles) return;
     const int n0col = ctile * BN;
 
-    const int TH = 1 << a.lgTH, TW = 1 << a.lgTW;
     const int tpi = a.tiles_x * a.tiles_y;
-    const int nimg0 = mtile >> a.lg_tpi, tin = mtile - nimg0 * tpi;
-    const int tyi = tin >> a.lg_tx, txi = tin - tyi * a.tiles_x;
-    const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+    const int nimg0 = mtile / tpi, tin = mtile - nimg0 * tpi;
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
+    const int ty0 = tyi * a.TH, tx0 = txi * a.TW;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -93,8 +92,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_h32(const ConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = 64 * w + 32 * mt + r;
-        const int ty = (m >> a.lgTW) & (TH - 1), tx = m & (TW - 1);
-        abase[mt] = (ty * a.PW + tx) * kRec + 16 * h;
+        int il, ty, tx;
+        tile_row(a, m, il, ty, tx);
+        abase[mt] = (il == 0 ? (ty * a.PW + tx) * kRec : 0) + 16 * h;      // (rows past TH * TW: a valid dummy record)
     }
     const int bbase = r * kRec + 16 * h;
 

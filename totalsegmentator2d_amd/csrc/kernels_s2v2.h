@@ -65,8 +65,9 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
 
     // ---- this workgroup's tiles: virtual block v = blockIdx.x + k * gridDim.x -> (xcd, column tile) fixed, pixel tile mtile0 + k * mstep
     const int xcd = blockIdx.x & 7, q80 = blockIdx.x >> 3;
-    const int ctile = q80 & (a.n_ctiles - 1), n0col = ctile * BN;
-    const int mtile0 = (q80 >> a.lg_nct) * 8 + xcd, mstep = ((int)(gridDim.x >> 3) >> a.lg_nct) * 8;
+    const int qm0 = q80 / a.n_ctiles;                       // (any tile count: round 5; the grid is a multiple of 8 * n_ctiles)
+    const int ctile = q80 - qm0 * a.n_ctiles, n0col = ctile * BN;
+    const int mtile0 = qm0 * 8 + xcd, mstep = ((int)(gridDim.x >> 3) / a.n_ctiles) * 8;
     if (mtile0 >= a.n_mtiles) return;
     const int ntl = (a.n_mtiles - 1 - mtile0) / mstep + 1;
     const int nchunks = a.C0 / 16;                         // the strided conv never reads a concat
@@ -126,8 +127,8 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     };
     auto tile_origin = [&](int k, int& nimg, int& tyi, int& txi, int& tin) {
         const int mtile = mtile0 + k * mstep;
-        nimg = mtile >> a.lg_tpi; tin = mtile - nimg * tpi;
-        tyi = tin >> a.lg_tx; txi = tin - tyi * a.tiles_x;
+        nimg = fdiv(mtile, a.inv_tpi); tin = mtile - nimg * tpi;
+        tyi = fdiv(tin, a.inv_tx); txi = tin - tyi * a.tiles_x;
     };
     const size_t img_px = (size_t)a.Hin * a.Win;
     // raw patch + scale / shift of one item in flight (fp32: 4 channels per thread -> nsa / nta only; fp16: 8 channels)

@@ -32,7 +32,7 @@ struct UpcArgs {
     const float* oscale;   // 1 / (common power-of-two pre-scale of wc and wk)
     float* dst; float* part;
     int B, H, W, Cout;     // output geometry (H % 8 == 0, W % 32 == 0)
-    int tiles_x, tiles_y, n_mtiles, n_ctiles, lg_nct, lg_tx, lg_tpi;
+    int tiles_x, tiles_y, n_mtiles, n_ctiles;
     float slope;
     unsigned long long* prof;   // diagnostic: phase cycle counters (6 entries) or nullptr
     int dbg;                    // experiment switches (TS2D_DBG; 0 in production)
@@ -50,14 +50,14 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = bid >> 3;
-    const int qm = q8 >> a.lg_nct;
+    const int qm = q8 / a.n_ctiles;                 // (any tile count: round 5)
     const int mtile = qm * 8 + xcd;
     const int ctile = q8 - qm * a.n_ctiles;
     if (mtile >= a.n_mtiles) return;
     const int n0col = ctile * BN;
     const int tpi = a.tiles_x * a.tiles_y;
-    const int nimg0 = mtile >> a.lg_tpi, tin = mtile - nimg0 * tpi;
-    const int tyi = tin >> a.lg_tx, txi = tin - tyi * a.tiles_x;
+    const int nimg0 = mtile / tpi, tin = mtile - nimg0 * tpi;
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
     const int ty0 = tyi << 3, tx0 = txi << 5;
 
     const int tid = threadIdx.x, lane = tid & 63;

@@ -38,14 +38,14 @@ __global__ __launch_bounds__(kUqThreads, 1) void conv3x3_upq(const UpcArgs a) {
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = bid >> 3;
-    const int qm = q8 >> a.lg_nct;
+    const int qm = q8 / a.n_ctiles;                 // (any tile count: round 5)
     const int mtile = qm * 8 + xcd;
     const int ctile = q8 - qm * a.n_ctiles;
     if (mtile >= a.n_mtiles) return;
     const int n0col = ctile * BN;
     const int tpi = a.tiles_x * a.tiles_y;
-    const int nimg0 = mtile >> a.lg_tpi, tin = mtile - nimg0 * tpi;
-    const int tyi = tin >> a.lg_tx, txi = tin - tyi * a.tiles_x;
+    const int nimg0 = mtile / tpi, tin = mtile - nimg0 * tpi;
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
     const int ty0 = tyi << 4, tx0 = txi << 5;               // 16 x 32 output pixels
 
     const int tid = threadIdx.x, lane = tid & 63;
