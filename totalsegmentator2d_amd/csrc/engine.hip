@@ -149,6 +149,7 @@ struct ts2d_engine {
     bool use_upc = true;          // "upc": decoder c0 blocks composed with their transposed conv (0: two kernels)
     bool use_res = true;          // "res": resident-weight kernel of the 32 -> 32 blocks
     bool use_fuse0 = true;        // "fuse0": first block recomputed inside the second (statistics-only pre-pass + conv3x3_res32 fused variant)
+    bool use_flex = true;         // "flex": the composed decoder entry on extent-following tiles at levels that are no multiple of 8 x 32 (0: two kernels there)
     int dbg = 0;                  // TS2D_DBG (the one environment switch left): timing ablations / in-kernel phase stamps of diagnostic runs
     unsigned long long* d_prof = nullptr;     // TS2D_DBG=256: in-kernel phase counters, 8 per op (diagnostic)
     std::vector<char> fused_away; // per op of the last run: 1 = its output tensor was not materialised (composed into the next op)
@@ -675,6 +676,30 @@ TileGeom tile_geom(int B, int Ht, int Wt, int sy, int sx, int taps) {
     return g;
 }
 
+// Tile of the composed decoder entry on a level that is no multiple of 8 x 32 (conv3x3_upc / conv3x3_upc_h, FLEX instances): TH x TW
+// output pixels, both even, <= 256, coarse patch (TH/2 + 2)(TW/2 + 2) <= 128 and skip patch (TH + 2)(TW + 2) <= 384 pixels (the
+// kernels' staging units); fewest tiles per image.  ok = false: no shape fills its tiles to 70 %.
+TileGeom tile_geom_upc(int B, int Ht, int Wt, bool& ok) {
+    ok = false;
+    TileGeom g{};
+    if (Ht % 2 || Wt % 2) return g;
+    int best_th = 0, best_tw = 0; long best = -1;
+    for (int tw = std::min(Wt, 128) / 2 * 2; tw >= 2; tw -= 2) {
+        int th = std::min(Ht, 256 / tw) / 2 * 2;
+        while (th >= 2 && ((th / 2 + 2) * (tw / 2 + 2) > 128 || (th + 2) * (tw + 2) > 384)) th -= 2;
+        if (th < 2) continue;
+        const int rows = (Ht + th - 1) / th;
+        th = ((Ht + rows - 1) / rows + 1) / 2 * 2;            // the smallest even TH with the same number of tile rows
+        const long tiles = (long)rows * ((Wt + tw - 1) / tw);
+        if (best < 0 || tiles < best) { best = tiles; best_th = th; best_tw = tw; }
+    }
+    if (best < 0 || (double)Ht * Wt < 0.70 * 256.0 * (double)best) return g;
+    ok = true;
+    g.TH = best_th; g.TW = best_tw; g.NIMG = 1;
+    tile_finish(g, B, Ht, Wt, 1, 1, 9);
+    return g;
+}
+
 // the 8 x 32 / 16 x 32 tilings of the kernels that walk complete tiles of a fixed shape
 TileGeom tile_fixed(int B, int Ht, int Wt, int th, int tw, int sy, int sx) {
     TileGeom g{};
@@ -842,9 +867,12 @@ struct Choice {
     int ksplit = 1;
     bool fused_stats = false;   // per-tile partial statistics come out of the kernel's epilogue (else stats_direct / splitk_reduce_stats)
     bool first_full = false;    // (K_FIRST*) complete one-image 256-pixel tiles: the persistent variant
+    bool flex = false;          // (K_UPC / K_UPC_H) the level is no multiple of 8 x 32: the FLEX instance on the extent-following tile c.g
 };
 
 inline bool fits32(size_t bytes) { return bytes < ((size_t)1 << 31); }      // an image addressed through a 32-bit buffer offset
+// the persistent kernels decode a tile number with udiv_magic (kernels.h): exact for tile number x tiles per image < 2^32
+inline bool magic_ok(const TileGeom& g) { return (unsigned long long)g.n_mtiles * (unsigned)(g.tiles_x * g.tiles_y) < 0x100000000ull; }
 
 // Does the first block run as a statistics-only pass, recomputed inside the second block (conv3x3_res32<.., FUSE>)?
 bool fuse0_applies(const ts2d_engine* e, int H, int W) {
@@ -868,7 +896,13 @@ Kern composed_kernel(const ts2d_engine* e, const Op& op, int B, int H, int W) {
                                                                                            //  before the workspace - and the pointers - exist)
     if (f16 && (op.cin_skip % 32 || !srcs_normed)) return K_NONE;       // (the 16-bit kernels walk the skip channels in chunks of 32 and normalise both sources)
     const int Ht = H >> op.ly, Wt = W >> op.lx;
-    if (Ht % 8 || Wt % 32) return K_NONE;                               // complete 8 x 32 tiles
+    if (Ht % 8 || Wt % 32) {                                            // no complete 8 x 32 tiles: tiles that follow the extent (FLEX instances)
+        bool ok = false;
+        (void)tile_geom_upc(B, Ht, Wt, ok);
+        if (!ok || !e->use_flex || !srcs_normed || op.cout % 32) return K_NONE;
+        if (!fits32((size_t)Ht * Wt * std::max(op.cout, op.cin_skip) * 4) || !fits32((size_t)(Ht / 2) * (Wt / 2) * up.cin * 4)) return K_NONE;
+        return f16 ? K_UPC_H : K_UPC;
+    }
     if (op.up0_ok && e->use_up0 && srcs_normed && fits32((size_t)Ht * Wt * 32 * 4)) return K_UP0;
     if (!fits32((size_t)Ht * Wt * std::max(op.cout, op.cin_skip) * 4) || !fits32((size_t)(Ht / 2) * (Wt / 2) * up.cin * 4)) return K_NONE;
     const int bn = op.cout % 64 == 0 ? 64 : 32;
@@ -919,7 +953,8 @@ Choice choose(const ts2d_engine* e, size_t oi, int B, int H, int W) {
         if (ck != K_NONE) {
             c.k = ck; c.fused_stats = true;
             c.bn = op.cout % 64 == 0 ? 64 : 32;
-            c.g = tile_fixed(B, Ht, Wt, (ck == K_UPQ || ck == K_UPC_H2) ? 16 : 8, 32, 1, 1);
+            if (Ht % 8 || Wt % 32) { bool ok = false; c.g = tile_geom_upc(B, Ht, Wt, ok); c.flex = true; }
+            else c.g = tile_fixed(B, Ht, Wt, (ck == K_UPQ || ck == K_UPC_H2) ? 16 : 8, 32, 1, 1);
             return c;
         }
     }
@@ -933,7 +968,7 @@ Choice choose(const ts2d_engine* e, size_t oi, int B, int H, int W) {
     }
     const bool img32 = fits32((size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4) && fits32((size_t)Ht * Wt * op.cout * 4);
     if (op.stride == 2) {
-        if (op.s2v2_ok && e->use_s2v2 && e->use_one && Ht % 8 == 0 && Wt % 32 == 0 && img32) {
+        if (op.s2v2_ok && e->use_s2v2 && e->use_one && Ht % 8 == 0 && Wt % 32 == 0 && img32 && magic_ok(tile_fixed(B, Ht, Wt, 8, 32, 2, 2))) {
             // stride-2 block on complete 8 x 32 output tiles: one 512-thread workgroup per CU, up to 128 output columns
             c.k = K_S2_V2; c.bn = op.bn2; c.fused_stats = true;
             c.g = tile_fixed(B, Ht, Wt, 8, 32, 2, 2);
@@ -969,7 +1004,10 @@ Choice choose(const ts2d_engine* e, size_t oi, int B, int H, int W) {
         return c;
     }
     const bool one = e->use_one && c.g.NIMG == 1 && P * 2 <= 3 * kBlock && img32;
-    if (one && e->use_q && tiles16 && c.bn == 64 && ct >= 64 && srcs_normed) {       // (pays off from 4 chunks on: measured)
+    if (one && e->use_q && tiles16 && c.bn == 64 && ct >= 64 && srcs_normed && magic_ok(tile_fixed(B, Ht, Wt, 16, 32, 1, 1))) {       // (pays off from 4 chunks on: measured)
+        // (round 5: an extent-following variant of this kernel was built and measured - tile = TH x TW <= 512 pixels, row -> pixel by division:
+        //  correct, but at 256 registers per wave its two extra address registers spill, and a scratch reload per item in front of the
+        //  MFMA stream made it 10-35 % SLOWER than conv3x3_f16x3_one on its extent-following 256-pixel tiles; ragged levels keep that kernel)
         c.k = K_S1_QP;                      // one persistent 512-thread workgroup per CU, patch and weights double-buffered
         c.g = tile_fixed(B, Ht, Wt, 16, 32, 1, 1);
         return c;
@@ -1199,7 +1237,8 @@ inline void set_tiling(ConvArgs& ca, const TileGeom& g, int n_ctiles) {
     ca.TH = g.TH; ca.TW = g.TW; ca.NIMG = g.NIMG; ca.lgTH = g.lgTH; ca.lgTW = g.lgTW;
     ca.inv_tw = 1.0f / (float)g.TW; ca.inv_thw = 1.0f / (float)(g.TH * g.TW);
     ca.tiles_x = g.tiles_x; ca.tiles_y = g.tiles_y; ca.n_mtiles = g.n_mtiles; ca.n_ctiles = n_ctiles;
-    ca.inv_tx = 1.0f / (float)g.tiles_x; ca.inv_tpi = 1.0f / (float)(g.tiles_x * g.tiles_y); ca.inv_nct = 1.0f / (float)n_ctiles;
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    ca.mg_tx = magic(g.tiles_x); ca.mg_tpi = magic(g.tiles_x * g.tiles_y);
     ca.PH = g.PH; ca.PW = g.PW;
 }
 
@@ -1299,6 +1338,8 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             ua.dst = dst.data; ua.part = e->d_part;
             ua.B = B; ua.H = Ht; ua.W = Wt; ua.Cout = op.cout;
             ua.tiles_x = g.tiles_x; ua.tiles_y = g.tiles_y; ua.n_mtiles = g.n_mtiles; ua.n_ctiles = op.cout / bn;
+            ua.TH = g.TH; ua.TW = g.TW; ua.inv_twc = 1.0f / (float)(g.TW / 2);
+            const bool flex = c.flex;                 // extent-following tile (the level is no multiple of 8 x 32): masked, division-addressed instance
             ua.slope = a.leaky_slope;
             ua.prof = prof; ua.dbg = e->dbg;
             const int grid = (ua.n_mtiles + 7) / 8 * 8 * ua.n_ctiles;
@@ -1339,9 +1380,11 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 const int ks = up.cin % 64 == 0 ? 4 : 2;
                 const size_t smem_h = std::max((size_t)ks * 2 * kUcPlane, (size_t)4 * kUsPlane + (size_t)2 * 9 * 2 * bn * 16);
                 prof_kernel(e, bn == 64 ? "conv3x3_upc_h<64>" : "conv3x3_upc_h<32>");
-#define TS2D_UPCH(BN_, KS_) do { static std::atomic<uint64_t> done_{0}; \
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h<BN_, KS_>), done_)); \
-                    hipLaunchKernelGGL((conv3x3_upc_h<BN_, KS_>), dim3(grid), dim3(kBlock), smem_h, st, ua); } while (0)
+#define TS2D_UPCH(BN_, KS_) do { static std::atomic<uint64_t> done_{0}, donef_{0}; \
+                    if (flex) { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h<BN_, KS_, true>), donef_)); \
+                                hipLaunchKernelGGL((conv3x3_upc_h<BN_, KS_, true>), dim3(grid), dim3(kBlock), smem_h, st, ua); } \
+                    else { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc_h<BN_, KS_>), done_)); \
+                           hipLaunchKernelGGL((conv3x3_upc_h<BN_, KS_>), dim3(grid), dim3(kBlock), smem_h, st, ua); } } while (0)
                 if (bn == 64) { if (ks == 4) TS2D_UPCH(64, 4); else TS2D_UPCH(64, 2); }
                 else { if (ks == 4) TS2D_UPCH(32, 4); else TS2D_UPCH(32, 2); }
 #undef TS2D_UPCH
@@ -1353,15 +1396,12 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             } else {
                 const size_t smem_u = std::max((size_t)8 * kUcPlane, (size_t)4 * kUsPlane + (size_t)9 * 4 * bn * 16);
                 prof_kernel(e, bn == 64 ? "conv3x3_upc<64>" : "conv3x3_upc<32>");
-                if (bn == 64) {
-                    static std::atomic<uint64_t> done64{0};
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<64>), done64));
-                    hipLaunchKernelGGL(conv3x3_upc<64>, dim3(grid), dim3(kBlock), smem_u, st, ua);
-                } else {
-                    static std::atomic<uint64_t> done32{0};
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<32>), done32));
-                    hipLaunchKernelGGL(conv3x3_upc<32>, dim3(grid), dim3(kBlock), smem_u, st, ua);
-                }
+#define TS2D_UPC(BN_, FLEX_) do { static std::atomic<uint64_t> done_{0}; \
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_upc<BN_, FLEX_>), done_)); \
+                    hipLaunchKernelGGL((conv3x3_upc<BN_, FLEX_>), dim3(grid), dim3(kBlock), smem_u, st, ua); } while (0)
+                if (bn == 64) { if (flex) TS2D_UPC(64, true); else TS2D_UPC(64, false); }
+                else { if (flex) TS2D_UPC(32, true); else TS2D_UPC(32, false); }
+#undef TS2D_UPC
             }
             HIP_TRY(hipGetLastError());
             TRY(prof_end(e, st));
@@ -1650,7 +1690,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
     struct B { const char* n; bool* p; };
     struct I { const char* n; int* p; int lo, hi; };
     const B bools[] = {{"h32", &e->use_h32}, {"one", &e->use_one}, {"s2v2", &e->use_s2v2}, {"q", &e->use_q}, {"h2", &e->use_h2},  {"uh2", &e->use_uh2},
-                       {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}};
+                       {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}, {"flex", &e->use_flex}};
     const I ints[] = {{"upq_min", &e->upq_min, 0, 1 << 20}, {"h2_min", &e->h2_min, 0, 1 << 20}, {"u0seg", &e->u0seg, 0, 1 << 20}};
     bool found = false;
     for (const B& b : bools) if (!strcmp(name, b.n)) { *b.p = value != 0; found = true; }
@@ -1658,7 +1698,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
         if (value < i.lo || value > i.hi) return fail(TS2D_ERR_INVALID, "option %s = %d out of range [%d, %d]", name, value, i.lo, i.hi);
         *i.p = value; found = true;
     }
-    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0)", name);
+    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0 flex)", name);
     e->ws_precision = -1;         // which ops compose (and with it the activation plan) depends on the options: re-plan at the next reserve / forward
     return TS2D_OK;
 }

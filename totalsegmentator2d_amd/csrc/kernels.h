@@ -74,6 +74,9 @@ constexpr int kBM = 256;      // output pixels per workgroup tile
 // n / d for 0 <= n < 2^22 by the float reciprocal inv_d = 1.0f / d (correctly rounded, computed on the host): exact, because
 // (n + 0.5) / d is at least 0.5 / d away from an integer and the two roundings move it by less than (n + 0.5) 2^-23 / d.
 __device__ __forceinline__ int fdiv(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
+// n / d for wave-uniform n with n * d < 2^32 by the multiplier mg = ceil(2^32 / d) (host; 0 stands for d == 1): ONE scalar
+// multiply-high.  Exact: mg d = 2^32 + e with 0 <= e < d, so n mg / 2^32 = n / d + n e / (d 2^32) and n e < 2^32 keeps the floor.
+__device__ __forceinline__ int udiv_magic(int n, unsigned mg) { return mg ? (int)__umulhi((unsigned)n, mg) : n; }
 
 // ------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain).
@@ -101,8 +104,8 @@ struct ConvArgs {
     int lgTH, lgTW;       // log2 of TH / TW when BOTH are powers of two, else -1 (the fast epilogues address a tile row with shifts)
     int tiles_x, tiles_y; // tiles per image
     int n_mtiles, n_ctiles;
-    float inv_tx, inv_tpi, inv_nct;      // 1 / tiles_x, 1 / (tiles_x * tiles_y), 1 / n_ctiles: the persistent kernels decode a tile number per item
-                                         // with fdiv() (any tile count: the power-of-two gate of rounds 1-4 is gone)
+    unsigned mg_tx, mg_tpi;      // ceil(2^32 / tiles_x), ceil(2^32 / (tiles_x * tiles_y)) (0 for a divisor of 1): the persistent kernels decode a tile
+                                 // number per item with udiv_magic() - scalar multiplies, any tile count (the power-of-two gate of rounds 1-4 is gone)
     int PH, PW;           // staged patch dims per image
     int KA, KB;           // transposed conv (conv_mfma_f32, TAPS == 1): kernel = stride (along H, along W); N = KA * KB * Cout
     float slope;

@@ -86,8 +86,8 @@ __global__ TS2D_PACKED_F32 __launch_bounds__(kQThreads, 1) void conv3x3_f16x3_qp
     };
     auto tile_origin = [&](int k, int& nimg, int& ty0, int& tx0, int& tin) {
         const int mtile = mtile0 + k * mstep;
-        nimg = fdiv(mtile, a.inv_tpi); tin = mtile - nimg * tpi;
-        const int tyi = fdiv(tin, a.inv_tx), txi = tin - tyi * a.tiles_x;
+        nimg = udiv_magic(mtile, a.mg_tpi); tin = mtile - nimg * tpi;
+        const int tyi = udiv_magic(tin, a.mg_tx), txi = tin - tyi * a.tiles_x;
         ty0 = tyi << 4; tx0 = txi << 5;
     };
 

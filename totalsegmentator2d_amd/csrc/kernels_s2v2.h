@@ -127,8 +127,8 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     };
     auto tile_origin = [&](int k, int& nimg, int& tyi, int& txi, int& tin) {
         const int mtile = mtile0 + k * mstep;
-        nimg = fdiv(mtile, a.inv_tpi); tin = mtile - nimg * tpi;
-        tyi = fdiv(tin, a.inv_tx); txi = tin - tyi * a.tiles_x;
+        nimg = udiv_magic(mtile, a.mg_tpi); tin = mtile - nimg * tpi;
+        tyi = udiv_magic(tin, a.mg_tx); txi = tin - tyi * a.tiles_x;
     };
     const size_t img_px = (size_t)a.Hin * a.Win;
     // raw patch + scale / shift of one item in flight (fp32: 4 channels per thread -> nsa / nta only; fp16: 8 channels)

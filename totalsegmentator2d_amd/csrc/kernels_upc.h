@@ -33,6 +33,8 @@ struct UpcArgs {
     float* dst; float* part;
     int B, H, W, Cout;     // output geometry (H % 8 == 0, W % 32 == 0)
     int tiles_x, tiles_y, n_mtiles, n_ctiles;
+    int TH, TW;            // FLEX instances: output tile TH x TW (both even, TH * TW <= 256); the fixed-tile instances walk 8 x 32 / 16 x 32
+    float inv_twc;         // 1 / (TW / 2)
     float slope;
     unsigned long long* prof;   // diagnostic: phase cycle counters (6 entries) or nullptr
     int dbg;                    // experiment switches (TS2D_DBG; 0 in production)
@@ -41,9 +43,28 @@ struct UpcArgs {
 constexpr int kUcPitch = 32, kUcSlots = 6 * kUcPitch, kUcPlane = kUcSlots * 16;        // coarse patch: 6 rows x 18 (pitch 32) slots
 constexpr int kUsPitch = 40, kUsSlots = 10 * kUsPitch, kUsPlane = kUsSlots * 16;       // skip patch: 10 rows x (17 even | 17 odd at +20)
 
-template <int BN>
+// Geometry of a composed tile.  FLEX = false: the 8 x 32 tile of rounds 2-4, every number a compile-time constant.  FLEX (round 5): the
+// tile follows the level's extent - TH x TW output pixels, both even, at most 256 - so that a level of 80 x 48 or 28 x 36 pixels
+// runs composed too (10 x 24 / 14 x 18 tiles) instead of as transposed conv + conv (the reference runs whatever patch size
+// plans.json names: ts2d/core/inference/prediction_worker.py:76-77).  A parity class of the tile is (TH / 2) x (TW / 2) <= 64 coarse
+// positions = the wave's two M tiles, row rho -> (I, J) = (rho / TWc, rho % TWc); both patches are stored densely (pitch = width).
+// Budgets (the engine checks): coarse patch (TH/2 + 2)(TW/2 + 2) <= 128 pixels (one staging unit per thread pair), skip patch
+// (TH + 2)(TW + 2) <= 384 pixels (three units).
+template <bool FLEX>
+struct UpcGeo {
+    int TH, TW, THc, TWc, C1W, C1N, P1, S2W, S2N, NE, P2, HO;
+    __device__ __forceinline__ UpcGeo(const UpcArgs& a) {
+        TH = FLEX ? a.TH : 8; TW = FLEX ? a.TW : 32; THc = TH >> 1; TWc = TW >> 1;
+        C1W = TWc + 2; C1N = (THc + 2) * C1W; P1 = FLEX ? C1W : kUcPitch;            // coarse patch: width, pixels, LDS row pitch
+        S2W = TW + 2; S2N = (TH + 2) * S2W; NE = TWc + 1;                              // skip patch: width, pixels, even (= odd) columns per row
+        P2 = FLEX ? S2W : kUsPitch; HO = FLEX ? NE : 20;                                // ... LDS row pitch, offset of the odd columns
+    }
+};
+
+template <int BN, bool FLEX = false>
 __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const UpcArgs a) {
     constexpr int NT = BN / 32;
+    const UpcGeo<FLEX> G(a);
     constexpr int WT1 = 4 * BN * 16;                        // bytes per "tap": [part][h][column]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -58,12 +79,21 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
     const int tpi = a.tiles_x * a.tiles_y;
     const int nimg0 = mtile / tpi, tin = mtile - nimg0 * tpi;
     const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
-    const int ty0 = tyi << 3, tx0 = txi << 5;
+    const int ty0 = FLEX ? tyi * G.TH : tyi << 3, tx0 = FLEX ? txi * G.TW : txi << 5;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), pA = w >> 1, pB = w & 1;      // this wave's output parity
     const int r = lane & 31, h = lane >> 5;
     const int octi = (lane >> 3) & 1, oct = octi * 8;
+    // FLEX: this lane's coarse position per M tile, (I, J) = (rho / TWc, rho % TWc) of row rho = 32 mt + r; rows past the class: (0, 0), masked later
+    int fI[2] = {0, 0}, fJ[2] = {0, 0};
+    if constexpr (FLEX) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int rho = 32 * mt + r;
+            if (rho < G.THc * G.TWc) { fI[mt] = fdiv(rho, a.inv_twc); fJ[mt] = rho - fI[mt] * G.TWc; }
+        }
+    }
 
     // LDS: phase 1 [coarse planes 8 x kUcPlane: 32-channel chunks]; phase 2 [skip planes 4 x kUsPlane | weights] (same memory)
     unsigned char* sB2 = smem8 + 4 * kUsPlane;
@@ -86,12 +116,12 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         const int Hc = a.H >> 1, Wc = a.W >> 1;
         // staging: one unit per thread: slot = 32 w + (lane & 7) + 8 (lane >> 4) of the 6 x 18 patch (row-major, 108 pixels), octet
         const int pp = 32 * w + (lane & 7) + 8 * (lane >> 4);
-        const int py = pp / 18, px = pp - py * 18;
+        const int py = pp / G.C1W, px = pp - py * G.C1W;
         const int iy = (ty0 >> 1) - 1 + py, ix = (tx0 >> 1) - 1 + px;
         // LDS planes of a 32-channel chunk: [k-step 2][part hi,lo][h][slot]: plane (ks, part, h) at ((ks * 2 + part) * 2 + h) * kUcPlane
-        const int lw = octi * kUcPlane + (py * kUcPitch + px) * 16;
+        const int lw = octi * kUcPlane + (py * G.P1 + px) * 16;
         unsigned vo = 0x80000000u;
-        if (pp < 108) {
+        if (pp < G.C1N) {
             if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) vo = (unsigned)(((iy * Wc + ix) * a.Cb + oct) * 4);
             else {
 #pragma unroll
@@ -113,6 +143,9 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         // fragments: M-tile row r = coarse position (I = 2 mt + (r >> 4), J = r & 15); tap (dI, dJ) reads coarse patch pixel
         // (I + pA + dI, J + pB + dJ)
         const int abase = h * kUcPlane + (((r >> 4) + pA) * kUcPitch + (r & 15) + pB) * 16;      // + ks * 4 planes + part * 2 planes + mt * 2 * pitch * 16 + (dI * pitch + dJ) * 16
+        int ab1[2];          // (per M tile: the FLEX row map has no uniform offset between the two)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ab1[mt] = FLEX ? h * kUcPlane + ((fI[mt] + pA) * G.P1 + fJ[mt] + pB) * 16 : abase + mt * 2 * kUcPitch * 16;
         // B fragments: the 4 taps of THIS wave's parity - no other wave of the workgroup reads them, so they do not go through
         // LDS (staging all 16 taps made this phase LDS-bound: 65 KB of weight writes per 48 MFMAs of a wave) but straight from
         // L2 into a ring of 4 tap sets, each reloaded for the next k-step right after its MFMAs are issued (4 taps of lookahead).
@@ -167,12 +200,12 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
                 const unsigned char* wnext = wgl + (size_t)knext * wchunk;
 #pragma unroll
                 for (int tap = 0; tap < 4; ++tap) {
-                    const int toff = ks * 4 * kUcPlane + ((tap >> 1) * kUcPitch + (tap & 1)) * 16;
+                    const int toff = ks * 4 * kUcPlane + ((tap >> 1) * G.P1 + (tap & 1)) * 16;
                     half8 ah[2], al[2];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        ah[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff);
-                        al[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff + 2 * kUcPlane);
+                        ah[mt] = *reinterpret_cast<const half8*>(smem8 + ab1[mt] + toff);
+                        al[mt] = *reinterpret_cast<const half8*>(smem8 + ab1[mt] + toff + 2 * kUcPlane);
                     }
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
@@ -212,12 +245,12 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         for (int it = 0; it < MAXU; ++it) {
             // unit enumeration: patch row, then its 17 even columns, then its 17 odd columns (LDS slots +20)
             const int q = 32 * (4 * it + w) + (lane & 7) + 8 * (lane >> 4);
-            const int py = q / 34, rem = q - py * 34;
-            const int half = rem >= 17 ? 1 : 0, idx = rem - 17 * half, px = 2 * idx + half;
+            const int py = q / G.S2W, rem = q - py * G.S2W;
+            const int half = rem >= G.NE ? 1 : 0, idx = rem - G.NE * half, px = 2 * idx + half;
             const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
             unsigned v = 0x80000000u;
-            lw[it] = octi * kUsPlane + (py * kUsPitch + 20 * half + idx) * 16;
-            if (q < 340) {
+            lw[it] = octi * kUsPlane + (py * G.P2 + G.HO * half + idx) * 16;
+            if (q < G.S2N) {
                 if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = (unsigned)(((iy * a.W + ix) * a.Cs + oct) * 4);
                 else { *reinterpret_cast<uint4*>(smem8 + lw[it]) = uint4{0u, 0u, 0u, 0u};
                        *reinterpret_cast<uint4*>(smem8 + lw[it] + 2 * kUsPlane) = uint4{0u, 0u, 0u, 0u}; }
@@ -239,10 +272,13 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         // fragments: row r = (I = 2 mt + (r >> 4), J = r & 15) -> output pixel (2I + pA, 2J + pB); tap (ky, kx) reads patch pixel
         // (2I + pA + ky, 2J + pB + kx): patch row 2I + pA + ky, column parity (pB + kx) & 1, index J + ((pB + kx) >> 1)
         const int abase = h * kUsPlane + ((2 * (r >> 4) + pA) * kUsPitch + (r & 15)) * 16;       // + mt * 4 * pitch * 16 + tap offset + part * 2 * Plane
+        int ab2[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ab2[mt] = FLEX ? h * kUsPlane + ((2 * fI[mt] + pA) * G.P2 + fJ[mt]) * 16 : abase + mt * 4 * kUsPitch * 16;
         const int bbase = 4 * kUsPlane + h * BN * 16 + r * 16;
         int tofs[3];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) tofs[kx] = ((((pB + kx) & 1) ? 20 : 0) + ((pB + kx) >> 1)) * 16;
+        for (int kx = 0; kx < 3; ++kx) tofs[kx] = ((((pB + kx) & 1) ? G.HO : 0) + ((pB + kx) >> 1)) * 16;
         for (int ch = 0; ch < nch; ++ch) {
             __syncthreads();
             TS2D_STAMP(3)
@@ -291,12 +327,12 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - 3 * ky;
-                const int toff = ky * kUsPitch * 16 + tofs[kx];
+                const int toff = ky * G.P2 * 16 + tofs[kx];
                 half8 ah[2], al[2], bh[NT], bl[NT];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    ah[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 4 * kUsPitch * 16 + toff);
-                    al[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 4 * kUsPitch * 16 + toff + 2 * kUsPlane);
+                    ah[mt] = *reinterpret_cast<const half8*>(smem8 + ab2[mt] + toff);
+                    al[mt] = *reinterpret_cast<const half8*>(smem8 + ab2[mt] + toff + 2 * kUsPlane);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -330,8 +366,9 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
     const float oscale = *a.oscale;
     const size_t img_el = (size_t)a.H * a.W * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(a.dst + (size_t)nimg0 * img_el, 0, (int)(img_el * 4), 0x00020000);
-    const bool edge = tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1;       // wave-uniform
+    const bool edge = FLEX || tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1;       // wave-uniform
     float st_s[NT], st_q[NT], st_k[NT];
+    float nvalid = 64.f;                                    // this wave's pixels inside the tile and the image
     // bias variants of this lane's channels, all loaded before the first store (a load per element serialised the 64 stores of a
     // wave behind 64 round trips to memory: measured 35 000 cycles per workgroup, in-kernel stamps of gpurun r2 upc_ph3; a load
     // between stores still waits - in-order vmcnt - for the stores ahead of it)
@@ -347,6 +384,41 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
             bv5[nt] = pb[5 * a.Cout]; bv6[nt] = pb[6 * a.Cout]; bv7[nt] = pb[7 * a.Cout]; bv8[nt] = pb[8 * a.Cout];
         }
     }
+    if constexpr (FLEX) {
+        // per row: (I, J) by division, output pixel (ty0 + 2 I + pA, tx0 + 2 J + pB); rows past the parity class or outside the image are
+        // dropped (out-of-range store offset) and kept out of the statistics; bias variant by the pixel's border position
+        const int ncls = G.THc * G.TWc;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { st_k[nt] = stat_pivot(__builtin_fmaf(acc_t[0][nt][0], oscale, bv4[nt])); st_s[nt] = 0.f; st_q[nt] = 0.f; }
+        int cnt = 0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int rho = 32 * mt + 4 * h + (i & 3) + 8 * (i >> 2);
+                asm volatile("" : "+v"(rho));              // (not hoisted into 32 live registers)
+                const int I = fdiv(rho, a.inv_twc), J = rho - I * G.TWc;
+                const int Y = ty0 + 2 * I + pA, X = tx0 + 2 * J + pB;
+                const bool ok = (rho < ncls) & (Y < a.H) & (X < a.W);
+                const unsigned vpix = ok ? (unsigned)(((Y * a.W + X) * a.Cout + n0col + r) * 4) : 0x80000000u;
+                cnt += ok ? 1 : 0;
+                const bool top = Y == 0, bot = Y == a.H - 1, lft = X == 0, rgt = X == a.W - 1;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float b0 = top ? bv0[nt] : (bot ? bv6[nt] : bv3[nt]);
+                    const float b1 = top ? bv1[nt] : (bot ? bv7[nt] : bv4[nt]);
+                    const float b2 = top ? bv2[nt] : (bot ? bv8[nt] : bv5[nt]);
+                    const float bv = lft ? b0 : (rgt ? b2 : b1);
+                    const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, vpix, nt * 128, 0);
+                    const float d = ok ? v - st_k[nt] : 0.f;
+                    st_s[nt] += d; st_q[nt] = __builtin_fmaf(d, d, st_q[nt]);
+                }
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        cnt += __shfl_xor(cnt, 32);
+        nvalid = (float)cnt;
+    } else {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
@@ -386,6 +458,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
         }
         st_s[nt] = s; st_q[nt] = q; st_k[nt] = kv;
     }
+    }
     TS2D_STAMP(4)
     lds_barrier();
     float* red = reinterpret_cast<float*>(smem8);
@@ -393,7 +466,7 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc(const Up
     for (int nt = 0; nt < NT; ++nt) {
         float s = st_s[nt], q = st_q[nt];
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-        if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], 64.f);
+        if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], nvalid);
     }
     TS2D_STAMP(5)
     lds_barrier();

@@ -11,9 +11,11 @@
 
 namespace ts2d {
 
-template <int BN, int KS>
+// FLEX: extent-following tiles, exactly as in conv3x3_upc (kernels_upc.h: UpcGeo).
+template <int BN, int KS, bool FLEX = false>
 __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const UpcArgs a) {
     constexpr int NT = BN / 32;
+    const UpcGeo<FLEX> G(a);
     constexpr int WT1 = 4 * BN * 16;                        // bytes per tap of the weight images: [hi, lo][h][column]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -29,12 +31,20 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
     const int tpi = a.tiles_x * a.tiles_y;
     const int nimg0 = mtile / tpi, tin = mtile - nimg0 * tpi;
     const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
-    const int ty0 = tyi << 3, tx0 = txi << 5;
+    const int ty0 = FLEX ? tyi * G.TH : tyi << 3, tx0 = FLEX ? txi * G.TW : txi << 5;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), pA = w >> 1, pB = w & 1;      // this wave's output parity
     const int r = lane & 31, h = lane >> 5;
     const int octi = (lane >> 3) & 1, oct = octi * 8;
+    int fI[2] = {0, 0}, fJ[2] = {0, 0};                     // FLEX: this lane's coarse position per M tile (kernels_upc.h)
+    if constexpr (FLEX) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int rho = 32 * mt + r;
+            if (rho < G.THc * G.TWc) { fI[mt] = fdiv(rho, a.inv_twc); fJ[mt] = rho - fI[mt] * G.TWc; }
+        }
+    }
     const _Float16 slope_h = (_Float16)a.slope;
     const unsigned slope2 = (unsigned)__builtin_bit_cast(unsigned short, slope_h) * 0x10001u;
 
@@ -50,11 +60,11 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
     {
         const int Hc = a.H >> 1, Wc = a.W >> 1;
         const int pp = 32 * w + (lane & 7) + 8 * (lane >> 4);              // pixel of the 6 x 18 coarse patch, octet (lane >> 3) & 1
-        const int py = pp / 18, px = pp - py * 18;
+        const int py = pp / G.C1W, px = pp - py * G.C1W;
         const int iy = (ty0 >> 1) - 1 + py, ix = (tx0 >> 1) - 1 + px;
-        const int lw = octi * kUcPlane + (py * kUcPitch + px) * 16;         // planes [k-step][h]
+        const int lw = octi * kUcPlane + (py * G.P1 + px) * 16;             // planes [k-step][h]
         unsigned vo = 0x80000000u;
-        if (pp < 108) {
+        if (pp < G.C1N) {
             if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc) vo = (unsigned)(((iy * Wc + ix) * a.Cb + oct) * 2);
             else {
 #pragma unroll
@@ -72,6 +82,9 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
         };
         prefetch(0);
         const int abase = h * kUcPlane + (((r >> 4) + pA) * kUcPitch + (r & 15) + pB) * 16;      // + ks * 2 planes + mt * 2 * pitch * 16 + (dI * pitch + dJ) * 16
+        int ab1[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ab1[mt] = FLEX ? h * kUcPlane + ((fI[mt] + pA) * G.P1 + fJ[mt] + pB) * 16 : abase + mt * 2 * kUcPitch * 16;
         const unsigned char* wgl = reinterpret_cast<const unsigned char*>(a.wc) + ((size_t)ctile * 16 + w * 4) * WT1 + h * BN * 16 + r * 16;
         const size_t wchunk = (size_t)a.n_ctiles * 16 * WT1;       // bytes per 16-channel k-step
         half8 rb[4][NT];                                            // this wave's 4 taps of the NEXT k-step to be used (ring, hi part only)
@@ -107,10 +120,10 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
                 const unsigned char* wnext = wgl + (size_t)knext * wchunk;
 #pragma unroll
                 for (int tap = 0; tap < 4; ++tap) {
-                    const int toff = ks * 2 * kUcPlane + ((tap >> 1) * kUcPitch + (tap & 1)) * 16;
+                    const int toff = ks * 2 * kUcPlane + ((tap >> 1) * G.P1 + (tap & 1)) * 16;
                     half8 ah[2];
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) ah[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kUcPitch * 16 + toff);
+                    for (int mt = 0; mt < 2; ++mt) ah[mt] = *reinterpret_cast<const half8*>(smem8 + ab1[mt] + toff);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -138,12 +151,12 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
 #pragma unroll
         for (int it = 0; it < MAXU; ++it) {
             const int q = 32 * (4 * it + w) + (lane & 7) + 8 * (lane >> 4);
-            const int py = q / 34, rem = q - py * 34;
-            const int half = rem >= 17 ? 1 : 0, idx = rem - 17 * half, px = 2 * idx + half;
+            const int py = q / G.S2W, rem = q - py * G.S2W;
+            const int half = rem >= G.NE ? 1 : 0, idx = rem - G.NE * half, px = 2 * idx + half;
             const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
             unsigned v = 0x80000000u;
-            lw[it] = octi * kUsPlane + (py * kUsPitch + 20 * half + idx) * 16;
-            if (q < 340) {
+            lw[it] = octi * kUsPlane + (py * G.P2 + G.HO * half + idx) * 16;
+            if (q < G.S2N) {
                 if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = (unsigned)(((iy * a.W + ix) * a.Cs + oct) * 2);
                 else { *reinterpret_cast<uint4*>(smem8 + lw[it]) = uint4{0u, 0u, 0u, 0u};
                        *reinterpret_cast<uint4*>(smem8 + lw[it] + 2 * kUsPlane) = uint4{0u, 0u, 0u, 0u}; }
@@ -164,10 +177,13 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
         };
         prefetch(0);
         const int abase = h * kUsPlane + ((2 * (r >> 4) + pA) * kUsPitch + (r & 15)) * 16;       // + ks * 2 planes + mt * 4 * pitch * 16 + tap offset
+        int ab2[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ab2[mt] = FLEX ? h * kUsPlane + ((2 * fI[mt] + pA) * G.P2 + fJ[mt]) * 16 : abase + mt * 4 * kUsPitch * 16;
         const int bbase = 4 * kUsPlane + h * BN * 16 + r * 16;                                   // + (ks * 9 + tap) * 2 BN 16 + nt * 512
         int tofs[3];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) tofs[kx] = ((((pB + kx) & 1) ? 20 : 0) + ((pB + kx) >> 1)) * 16;
+        for (int kx = 0; kx < 3; ++kx) tofs[kx] = ((((pB + kx) & 1) ? G.HO : 0) + ((pB + kx) >> 1)) * 16;
         for (int ch = 0; ch < nch; ++ch) {
             __syncthreads();
             // weights of this chunk: 2 k-steps x 9 taps x the hi part [h][column] (2 BN slots per tap, contiguous in the image)
@@ -208,10 +224,10 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int ky = tap / 3, kx = tap - 3 * ky;
-                    const int toff = ks * 2 * kUsPlane + ky * kUsPitch * 16 + tofs[kx];
+                    const int toff = ks * 2 * kUsPlane + ky * G.P2 * 16 + tofs[kx];
                     half8 ah[2], bh[NT];
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) ah[mt] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 4 * kUsPitch * 16 + toff);
+                    for (int mt = 0; mt < 2; ++mt) ah[mt] = *reinterpret_cast<const half8*>(smem8 + ab2[mt] + toff);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bh[nt] = *reinterpret_cast<const half8*>(smem8 + bbase + (ks * 9 + tap) * 2 * BN * 16 + nt * 512);
 #pragma unroll
@@ -231,8 +247,9 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
     const float oscale = *a.oscale;
     const size_t img_el = (size_t)a.H * a.W * a.Cout;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * 2), 0x00020000);
-    const bool edge = tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1;       // wave-uniform
+    const bool edge = FLEX || tyi == 0 || tyi == a.tiles_y - 1 || txi == 0 || txi == a.tiles_x - 1;       // wave-uniform
     float st_s[NT], st_q[NT], st_k[NT];
+    float nvalid = 64.f;
     float bv0[NT], bv1[NT], bv2[NT], bv3[NT], bv4[NT], bv5[NT], bv6[NT], bv7[NT], bv8[NT];       // (nine arrays: see kernels_upc.h)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -244,6 +261,39 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
             bv5[nt] = pb[5 * a.Cout]; bv6[nt] = pb[6 * a.Cout]; bv7[nt] = pb[7 * a.Cout]; bv8[nt] = pb[8 * a.Cout];
         }
     }
+    if constexpr (FLEX) {          // (the epilogue of conv3x3_upc<.., FLEX>, fp16 stores)
+        const int ncls = G.THc * G.TWc;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { st_k[nt] = stat_pivot(round_act<ST>(__builtin_fmaf(acc_t[0][nt][0], oscale, bv4[nt]))); st_s[nt] = 0.f; st_q[nt] = 0.f; }
+        int cnt = 0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int rho = 32 * mt + 4 * h + (i & 3) + 8 * (i >> 2);
+                asm volatile("" : "+v"(rho));
+                const int I = fdiv(rho, a.inv_twc), J = rho - I * G.TWc;
+                const int Y = ty0 + 2 * I + pA, X = tx0 + 2 * J + pB;
+                const bool ok = (rho < ncls) & (Y < a.H) & (X < a.W);
+                const unsigned vpix = ok ? (unsigned)(((Y * a.W + X) * a.Cout + n0col + r) * 2) : 0x80000000u;
+                cnt += ok ? 1 : 0;
+                const bool top = Y == 0, bot = Y == a.H - 1, lft = X == 0, rgt = X == a.W - 1;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float b0 = top ? bv0[nt] : (bot ? bv6[nt] : bv3[nt]);
+                    const float b1 = top ? bv1[nt] : (bot ? bv7[nt] : bv4[nt]);
+                    const float b2 = top ? bv2[nt] : (bot ? bv8[nt] : bv5[nt]);
+                    const float bv = lft ? b0 : (rgt ? b2 : b1);
+                    const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
+                    buffer_store_act<ST>(v, rsd, vpix, nt * 64);
+                    const float d = ok ? round_act<ST>(v) - st_k[nt] : 0.f;
+                    st_s[nt] += d; st_q[nt] = __builtin_fmaf(d, d, st_q[nt]);
+                }
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        cnt += __shfl_xor(cnt, 32);
+        nvalid = (float)cnt;
+    } else {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0col + nt * 32 + r;
@@ -273,13 +323,14 @@ __global__ __launch_bounds__(kBlock, BN == 32 ? 3 : 2) void conv3x3_upc_h(const 
         }
         st_s[nt] = s; st_q[nt] = q; st_k[nt] = kv;
     }
+    }
     lds_barrier();
     float* red = reinterpret_cast<float*>(smem8);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         float s = st_s[nt], q = st_q[nt];
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-        if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], 64.f);
+        if (h == 0) stat_wave_put(red, w * BN + nt * 32 + r, s, q, st_k[nt], nvalid);
     }
     lds_barrier();
     if (tid < BN) stat_tile_store(red, 4, BN, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 4);
