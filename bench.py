@@ -118,6 +118,115 @@ def oracle_check(arch, sd, x4, logits4, mask4, emulate=None):
     return errs, flips, bits, worst, all_tol
 
 
+def timed_forward(torch, dev, fn, rounds=3, reps=3):
+    """Median over `rounds` of the mean device time of `reps` back-to-back calls (torch events on the current stream), ms."""
+    fn(); fn()
+    torch.cuda.synchronize(dev)
+    ts = []
+    st = torch.cuda.current_stream(dev)
+    for _ in range(rounds):
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record(st)
+        for _ in range(reps):
+            fn()
+        t1.record(st)
+        torch.cuda.synchronize(dev)
+        ts.append(t0.elapsed_time(t1) / reps)
+    return float(np.median(ts))
+
+
+def geometry_leg(torch, dev, engine, arch, B, H, W, modes=('split', 'f16')):
+    """Throughput and kernel dispatch of `engine` on a B x C x H x W batch (logits + packed masks out, inputs resident), per mode:
+    slices/s, Mpixel/s and the kernel that served every op.  The reference runs whatever patch size / pooling plans.json names
+    (ts2d/core/inference/prediction_worker.py:76-77, nnu.py:164-165); 512 x 512 is this repo's ASSUMPTION."""
+    x = torch.randn(B, arch.input_channels, H, W, device=dev)
+    lg = torch.empty(B, arch.num_classes, H, W, device=dev)
+    mk = torch.empty(B, arch.num_classes, H, W // 32, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {'batch': B, 'H': H, 'W': W, 'n_stages': arch.n_stages, 'strides_last': list(arch.strides[-1]),
+           'gflop_per_slice': round(arch.work(H, W)['flops'] / 1e9, 2)}
+    for mode in modes:
+        engine.set_precision(mode)
+        engine.set_profiling(False)
+        ms = timed_forward(torch, dev, lambda: engine.forward(x, logits=True, mask=True, out_logits=lg, out_mask=mk, stream=stream))
+        engine.set_profiling(True)
+        engine.forward(x, logits=True, mask=True, out_logits=lg, out_mask=mk, stream=stream)
+        torch.cuda.synchronize(dev)
+        kern = {k: v for k, v in engine.op_kernels().items() if not k.endswith('.stats')}
+        engine.set_profiling(False)
+        out[mode] = {'ms_per_step': round(ms, 3), 'slices_per_s': round(B / ms * 1e3, 1), 'mpixel_per_s': round(B * H * W / ms * 1e-3, 1),
+                     'tflops': round(B / ms * 1e3 * arch.work(H, W)['flops'] / 1e12, 1), 'kernels': kern}
+    del x, lg, mk
+    return out
+
+
+def config3_leg(torch, dev, local_rank, body_sd, B=128, steps=3):
+    """BASELINE configs[2] inside the default line: the five ts2d-v2 sub-models (K = 18/23/24/26/26 -> 117 mask channels) on one batch of
+    128 slices, one shared activation workspace, 16-bit mode, packed masks out.  (The reference drives its five sub-models per case
+    one after the other: ts2d/tool.py:110-112.)  Throughput does not depend on the weight values: the four other sub-models reuse
+    sub-model 1's body tensors with heads of their own (generating five 46 M-parameter sets costs 40 s of host time; `--workload
+    config3` and the tests use five independent sets)."""
+    from totalsegmentator2d_amd import parallel, weights
+    from totalsegmentator2d_amd.arch import UNetArch
+    from totalsegmentator2d_amd.submodels import SubModelSet, TS2D_V2_HEADS
+    models = []
+    for i, mid in enumerate(sorted(TS2D_V2_HEADS)):
+        a = UNetArch.canonical(num_classes=TS2D_V2_HEADS[mid])
+        sd = dict(body_sd)
+        for t, (key, shp) in enumerate(a.param_specs()):
+            if 'seg_layers' in key:
+                sd[key] = weights.prng.normal_f32(i + 1, t, shp, mean=0.0, std=0.05 if key.endswith('weight') else 0.01)
+        models.append((mid, a, weights.pack_blob(a, sd)))
+    x = parallel.synth_slices(local_rank, 0, 0, B, (2, 512, 512))
+    res = {'workload': 'BASELINE configs[2]: full ts2d-v2 (5 sub-models, 117 labels), batch=128, 1xMI355X, packed masks out', 'batch': B}
+    with SubModelSet(models, device=local_rank, precision='f16') as ms:
+        ms.reserve(B, 512, 512)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        masks = ms.forward_masks(x, stream=stream)
+        work = sum(e.arch.work(512, 512)['flops'] for e in ms.engines)
+        for mode in ('f16', 'split'):
+            ms.set_precision(mode)
+            t = timed_forward(torch, dev, lambda: ms.forward_masks(x, masks, stream=stream), rounds=steps, reps=1)
+            res[mode] = {'ms_per_batch': round(t, 2), 'value': round(B / t * 1e3, 1), 'unit': 'slices/s (all five sub-models)',
+                         'sub_model_forwards_per_s': round(5 * B / t * 1e3, 1), 'tflops': round(B / t * 1e3 * work / 1e12, 1)}
+        res['labels'] = int(sum(ms.channels))
+    del x, masks
+    return res
+
+
+def config5_leg(torch, dev, local_rank, B=32):
+    """BASELINE configs[4] geometry on one GPU: tsxr X-ray path, 1 x 1024 x 1024, 9 stages, K = 26 (ribs: the reference's xr test model,
+    ts2d/data/config.json:4), 16-bit and split modes, packed masks out: images/s, TFLOP/s and the stride-1 3x3 family's fraction of
+    the MFMA peak (HIP events of one profiled forward)."""
+    from totalsegmentator2d_amd import weights
+    from totalsegmentator2d_amd.arch import UNetArch, OP_CONV3X3
+    from totalsegmentator2d_amd.engine import Engine
+    a = UNetArch.canonical(input_channels=1, num_classes=26, n_stages=9)
+    w = a.work(1024, 1024)
+    fam = {o['name']: 2.0 * m['macs'] for o, m in zip(a.program(), w['per_layer'])
+           if o['op'] == OP_CONV3X3 and tuple(o['stride']) == (1, 1) and o['src'] != 'input'}
+    res = {'workload': 'BASELINE configs[4] on one GPU: tsxr 1x1024x1024, 9 stages, K=26, packed masks out', 'batch': B,
+           'gflop_per_image': round(w['flops'] / 1e9, 2)}
+    with Engine(a, weights.pack_blob(a, weights.synthetic_state_dict(a, 7)), device=local_rank) as e:
+        x = torch.randn(B, 1, 1024, 1024, device=dev)
+        m = torch.empty(B, 26, 1024, 32, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for mode, peak in (('f16', PEAK_F16_MFMA_TFLOPS), ('split', PEAK_F16_MFMA_TFLOPS / 3.0)):
+            e.set_precision(mode)
+            t = timed_forward(torch, dev, lambda: e.forward(x, logits=False, mask=True, out_mask=m, stream=stream), rounds=3, reps=1)
+            e.set_profiling(True)
+            e.forward(x, logits=False, mask=True, out_mask=m, stream=stream)
+            torch.cuda.synchronize(dev)
+            ot = e.op_times()
+            e.set_profiling(False)
+            fms = sum(v for k, v in ot.items() if k in fam)
+            ftf = sum(fam.values()) * B / (fms * 1e-3) / 1e12
+            res[mode] = {'ms_per_batch': round(t, 2), 'value': round(B / t * 1e3, 1), 'unit': 'images/s', 'tflops': round(B / t * 1e3 * w['flops'] / 1e12, 1),
+                         'stride1_family': {'ms': round(fms, 3), 'achieved_tflops': round(ftf, 1), 'peak': round(peak, 1), 'frac': round(ftf / peak, 4)}}
+        del x, m
+    return res
+
+
 def run_config3(args, torch, dev, local_rank):
     """BASELINE config 3: full ts2d-v2 (5 sub-models, 117 labels), batch 128, one MI355X, 16-bit mode."""
     from totalsegmentator2d_amd import parallel, weights
@@ -239,6 +348,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--no-other-modes', action='store_true', help='skip the exact / f16 legs (profiling runs: only the timed mode launches kernels)')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip the geometry / config3 / config5 legs of the default line')
     ap.add_argument('--workload', choices=('config2', 'config3', 'config4'), default='config2')
     ap.add_argument('--stream', type=int, default=None, help='config 4: total slices of the synthetic stream (default 10000)')
     ap.add_argument('--precision', choices=('split', 'exact', 'f16'), default=None,
@@ -304,6 +414,18 @@ def main():
             la, _ = engine.forward(xa); lb, _ = replica.forward(xa); torch.cuda.synchronize(dev)
             assert torch.equal(la, lb), 'replica filled through the broadcast hook differs'
             replica.close()
+    ranks_seen = None
+    if multi:
+        # (rank, device index, PCI bus id) of every rank, gathered over the process group: a SCALE line shows that RCCL saw N ranks on N devices
+        try:
+            bus = torch.cuda.get_device_properties(local_rank)
+            mine = [rank, local_rank, int(getattr(bus, 'pci_bus_id', -1)), int(getattr(bus, 'pci_device_id', -1)), int(getattr(bus, 'pci_domain_id', -1))]
+        except Exception:                                                  # noqa: BLE001
+            mine = [rank, local_rank, -1, -1, -1]
+        t = torch.tensor(mine, dtype=torch.int64, device=dev)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        ranks_seen = [{'rank': int(g[0]), 'device': int(g[1]), 'pci': f'{int(g[4]):04x}:{int(g[2]):02x}:{int(g[3]):02x}' if int(g[2]) >= 0 else None} for g in got]
     if args.workload == 'config4':
         total = args.stream if args.stream is not None else 10000
         r4 = run_config4(args, torch, dev, engine, rank, world, total, batch=B)
@@ -319,7 +441,7 @@ def main():
                                           'packed masks of the whole stream kept', 'stream_slices': total, 'batch_per_step': B,
                               'parallelism': f'slice-dp{world}', 'gflop_per_slice': round(work['flops'] / 1e9, 2)},
                    'weight_broadcast_ms': None if bcast_ms is None else round(bcast_ms, 2), 'precision_mode': args.precision,
-                   'tflops': round(r4['value'] * work['flops'] / 1e12, 2)}
+                   'tflops': round(r4['value'] * work['flops'] / 1e12, 2), 'ranks_seen': ranks_seen}
             print(json.dumps(out), flush=True)
         engine.close()
         if multi:
@@ -402,6 +524,8 @@ def main():
         }
         if bcast_ms is not None:
             out['weight_broadcast_ms'] = round(bcast_ms, 2)
+        if ranks_seen is not None:
+            out['ranks_seen'] = ranks_seen
         if stream_res is not None:
             out['stream_10k'] = dict(stream_res, workload='BASELINE configs[3]: 10k-slice stream, contiguous blocks per rank (strong scaling)')
         split = args.precision == 'split'
@@ -469,7 +593,10 @@ def main():
                                               'all_conv3x3_ms_per_step': round(sum(ms[k] for k in all3 if k in ms), 3)}
             # (c) level 0 + head: HBM-bound.  Algorithmic bytes = one read of every input (no halo), one write of the output.
             esz = 2 if args.precision == 'f16' else 4
-            l0 = {}
+            l0, l0_moved = {}, {}
+            # with the first block fused into the second (conv3x3_first_stats + conv3x3_res32f) enc0.c0's output is never written and never
+            # read: the MOVED bytes leave both out (the statistics pass and the fused block each read the network input instead)
+            fused0 = op_kernels.get('enc0.c0') == 'conv3x3_first_stats'
             for n, (o, m) in layer.items():
                 if o['level'] == 0 and n in ms:
                     cin = o['cin'] + o.get('cin_skip', 0)
@@ -479,10 +606,21 @@ def main():
                         rd = ((H * W) // 4 * layer[n.replace('.c0', '.up')][0]['cin'] + H * W * o['cin_skip']) * esz
                     wr = H * W * o['cout'] * (4 if n == 'head' else esz)
                     l0[n] = (rd + wr) * B
+                    mrd, mwr = rd, wr
+                    if fused0 and n == 'enc0.c0':
+                        mwr = 0
+                    if fused0 and n == 'enc0.c1':
+                        mrd = H * W * arch.input_channels * 4
+                    l0_moved[n] = (mrd + mwr) * B
             l0_ms = sum(ms[k] for k in l0)
             l0_gbs = sum(l0.values()) / (l0_ms * 1e-3) / 1e9
+            l0_mgbs = sum(l0_moved.values()) / (l0_ms * 1e-3) / 1e9
             out['roofline_level0'] = {'bound': 'hbm', 'achieved': round(l0_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                       'frac': round(l0_gbs / PEAK_HBM_GBS, 4), 'ops': sorted(l0), 'ms_per_step': round(l0_ms, 3),
+                                      'moved': {'achieved': round(l0_mgbs, 1), 'frac': round(l0_mgbs / PEAK_HBM_GBS, 4), 'first_block_fused': fused0,
+                                                'gb_per_step': round(sum(l0_moved.values()) / 1e9, 2), 'algorithmic_gb_per_step': round(sum(l0.values()) / 1e9, 2),
+                                                'note': 'bytes the kernels actually move: enc0.c0 output neither written nor read when the first block is '
+                                                        'recomputed inside the second; `achieved` above charges the layer-wise (reference) bytes'},
                                       'frac_of_measured_mixed_read_write_rate': round(l0_gbs / MEASURED_HBM_MIXED_GBS, 4),
                                       'note': 'scripts/probes/hbm_probe.hip on this pool: read-only 6.47, write-only 5.6, copy 4.7, 4:3 read:write '
                                               '4.6 TB/s; the achieved figure counts algorithmic bytes (halo re-reads not included)'}
@@ -558,6 +696,38 @@ def main():
                                            'frac': round(hv * w16['act_bytes'] / 1e9 / PEAK_HBM_GBS, 4),
                                            'act_mb_per_slice': round(w16['act_bytes'] / 1e6, 1)}}
             engine.set_precision(args.precision)
+        if world == 1 and not args.no_other_modes and not args.no_extra_legs:
+            # ---- other extents and BASELINE configurations, outside the timed region (VERDICT r4 next #1c / #2)
+            del logits, mask
+            ref_mp = {'split': None, 'f16': None}
+            geo = {'note': 'same engine / step definition as the headline (logits + packed masks out, inputs resident, B per GPU as given); '
+                           'mpixel_per_s = B H W / time; ratio_to_512 = Mpixel/s relative to the 512 x 512 figure of the same mode in this block'}
+            try:
+                g512 = geometry_leg(torch, dev, engine, arch, B, 512, 512)
+                for mode in ref_mp:
+                    ref_mp[mode] = g512[mode]['mpixel_per_s']
+                    g512[mode].pop('kernels')
+                geo['512x512'] = g512
+                g = geometry_leg(torch, dev, engine, arch, B, 640, 384)
+                geo['640x384'] = g
+                a7 = UNetArch.canonical(input_channels=2, num_classes=18, n_stages=7)
+                with Engine(a7, weights.pack_blob(a7, weights.synthetic_state_dict(a7, seed=1)), device=local_rank) as e7:
+                    geo['448x576_7stages'] = geometry_leg(torch, dev, e7, a7, B, 448, 576)
+                for k in ('640x384', '448x576_7stages'):
+                    for mode in ref_mp:
+                        geo[k][mode]['ratio_to_512'] = round(geo[k][mode]['mpixel_per_s'] / ref_mp[mode], 4)
+            except Exception as ex:                                        # noqa: BLE001 - reported, the headline is printed either way
+                geo['error'] = f'{type(ex).__name__}: {ex}'
+            out['geometry'] = geo
+            engine.set_precision(args.precision)
+            engine.reserve(B, H, W)
+            for name, leg in (('config3', lambda: config3_leg(torch, dev, local_rank, sd)), ('config5', lambda: config5_leg(torch, dev, local_rank))):
+                try:
+                    out[name] = leg()
+                except Exception as ex:                                    # noqa: BLE001
+                    out[name] = {'error': f'{type(ex).__name__}: {ex}'}
+            logits = torch.empty(B, arch.num_classes, H, W, device=dev)
+            mask = torch.empty(B, arch.num_classes, H, W // 32, dtype=torch.int32, device=dev)
         if world == 1 and not args.no_cpu_baseline:
             step(); torch.cuda.synchronize(dev)
             idx = [0, B // 3, (2 * B) // 3, B - 1] if B >= 4 else list(range(B))

@@ -9,7 +9,7 @@ O=$R/${1:-gpurun_out/prof}
 mkdir -p "$O"
 python3 "$R/bench.py" > "$O/bench.json" 2> "$O/bench.err"
 cd /tmp && export TMPDIR=/tmp
-A="--steps 2 --warmup 1 --no-cpu-baseline --no-other-modes --no-profile"
+A="--steps 10 --warmup 3 --no-cpu-baseline --no-other-modes --no-profile"      # (13 forwards: one cold launch no longer carries 4-8 % of a kernel's average - VERDICT r4 weak #11)
 F="--output-format csv"
 timeout -k 10 250 rocprofv3 --kernel-trace --stats $F -d "$O/prof_kt" -o runc -- python3 "$R/bench.py" $A > "$O/prof_kt.log" 2>&1
 timeout -k 10 250 rocprofv3 --kernel-trace --pmc FETCH_SIZE $F -d "$O/pmc_fetch" -o runc -- python3 "$R/bench.py" $A > "$O/pmc_fetch.log" 2>&1

@@ -38,19 +38,31 @@ class SubModelSet:
         lo = sum(self.channels[:i])
         return lo, lo + self.channels[i]
 
+    def set_precision(self, mode: str):
+        """Arithmetic mode of every sub-model; the shared workspace is re-sized at the next forward (a mode's activation plan differs)."""
+        for e in self.engines:
+            e.set_precision(mode)
+        self._reserved = None
+
     def reserve(self, B: int, H: int, W: int):
         """One workspace of the largest engine's size, shared by all sub-models (the reference drives them sequentially,
-        ``ts2d/tool.py:110-112``; here they follow each other on one stream): 1x instead of 5x the activation memory."""
+        ``ts2d/tool.py:110-112``; here they follow each other on one stream): 1x instead of 5x the activation memory.
+        Sized under the engines' CURRENT precision mode / options / keep flag; grown when any of them needs more."""
         import torch
         need = max(e.workspace_bytes(B, H, W) for e in self.engines)
-        if self._ws is None or self._ws.numel() < need:
+        if self._ws is None or self._ws.numel() < need + 256:
             for e in self.engines:
                 e.set_workspace(None)
             self._ws = None
+            self._ws_set = None
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=torch.device('cuda', self.engines[0].device))
         base = (self._ws.data_ptr() + 255) // 256 * 256
+        size = self._ws.numel() - (base - self._ws.data_ptr())
+        if getattr(self, '_ws_set', None) != (base, size):          # (set_workspace synchronises twice per engine and invalidates its plan: only on change)
+            for e in self.engines:
+                e.set_workspace(base, size)
+            self._ws_set = (base, size)
         for e in self.engines:
-            e.set_workspace(base, self._ws.numel() - (base - self._ws.data_ptr()))
             e.reserve(B, H, W)
         self._reserved = (B, H, W)
 
@@ -60,7 +72,8 @@ class SubModelSet:
         import torch
         B, _, H, W = x.shape
         r = getattr(self, '_reserved', None)
-        if r is None or r[0] < B or r[1:] != (H, W):
+        # (a member engine's mode / options / keep flag may have changed since the last reserve: its need is re-read before every run)
+        if r is None or r[0] < B or r[1:] != (H, W) or max(e.workspace_bytes(B, H, W) for e in self.engines) + 256 > self._ws.numel():
             self.reserve(B, H, W)
         if out_masks is None:
             out_masks = [torch.empty((B, k, H, W // 32), dtype=torch.int32, device=x.device) for k in self.channels]
