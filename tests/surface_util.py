@@ -4,6 +4,13 @@ import numpy as np
 from tests import cases
 from totalsegmentator2d_amd import weights
 from totalsegmentator2d_amd.model import HIPModel
+from tests.host_predictor import HostLogicPredictor
+
+
+class HostModel(HIPModel):
+    """The model surface on a machine without a GPU: its predictor is the host restatement fed by the torch oracle."""
+    def _make_predictor(self, kw):
+        return HostLogicPredictor(network=self._config['oracle_network'], **kw)
 
 
 def synthetic_model(mid, K, seed, channels=('mean', 'max'), patch=(64, 64), network=None, mirror=True, feats=(32, 32, 64)):
@@ -17,5 +24,6 @@ def synthetic_model(mid, K, seed, channels=('mean', 'max'), patch=(64, 64), netw
            'synthetic': {'arch': arch, 'blobs': [blob], 'patch_size': patch, 'dataset_json': ds}}
     if network is not None:
         from oracle import torch_oracle as O
-        cfg['network'] = lambda batch, fold=0: np.concatenate([O.unet_forward(arch, sd, batch[i:i + 1]).numpy() for i in range(batch.shape[0])])
+        cfg['oracle_network'] = lambda batch, fold=0: np.concatenate([O.unet_forward(arch, sd, batch[i:i + 1]).numpy() for i in range(batch.shape[0])])
+        return HostModel(cfg), arch, sd
     return HIPModel(cfg), arch, sd

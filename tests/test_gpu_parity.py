@@ -371,6 +371,33 @@ def test_canonical_widths_on_extents_other_than_512(H, W, strides):
         assert not {n: k for n, k in lv16.items() if k in ('conv3x3_f16x3', 'conv3x3s2_f16x3')} and not any(n.endswith('.up') for n in lv16), lv16
 
 
+def test_f16_per_layer_oracle_on_the_256_and_512_channel_kernels_of_the_canonical_net():
+    """the per-layer 16-bit oracle check reached conv3x3_h2 / conv3x3_upc_h2 only on a net whose 256- / 512-channel
+    blocks run at 16 x 16 and 8 x 8 (other kernels).  Here: the canonical net at 512 x 512, B = 1 - enc3.c1 / enc4.c1 / dec4.c1
+    (conv3x3_h2 with 4 / 8 column tiles) and dec3.c0 / dec4.c0 (conv3x3_upc_h2: KS = 4, the 8-chunk weight-DMA ring), each block
+    from the engine's OWN inputs of that block against ONE block of the 16-bit oracle, bounds rms 1e-4 / 7e-4."""
+    from oracle import torch_oracle as O
+    arch = UNetArch.canonical()
+    sd, blob = blob_for(arch, 1)
+    x = cases.make_input(arch, 1, 512, 512, 1)
+    prog = {o['name']: o for o in arch.program()}
+    want_kernel = {'enc3.c1': 'conv3x3_h2', 'enc4.c1': 'conv3x3_h2', 'dec4.c1': 'conv3x3_h2', 'dec3.c0': 'conv3x3_upc_h2', 'dec4.c0': 'conv3x3_upc_h2',
+                   'dec2.c0': 'conv3x3_upc_h2', 'enc2.c1': 'conv3x3_h2'}
+    with Engine(arch, blob) as e:
+        e.set_precision('f16')
+        e.set_profiling(True)
+        e.forward(x, logits=True)
+        kern = e.op_kernels()
+        for n, k in want_kernel.items():
+            assert kern[n] == k, (n, kern[n])
+            o = prog[n]
+            ins = (prog[n.replace('.c0', '.up')]['src'], o['skip']) if n.endswith('.c0') else (o['src'],)
+            srcs = [e.debug_tensor(i) for i in ins]
+            got = e.debug_tensor(n)
+            want = O.layer_forward(arch, sd, n, *srcs, emulate='f16', storage_view=True).numpy()
+            assert got.shape == want.shape and _f16_layer_ok(n, got, want), (n, float(np.abs(got - want).max()), float(np.sqrt(np.mean((got - want) ** 2))))
+
+
 def test_config3_config5_in_f16():
     """Config 3 (a 26-head sub-model, 512x512) and config 5 (tsxr: 1-channel 1024x1024, 9 stages) in the 16-bit mode, against the
     16-bit oracle (tight) and the fp32 oracle (what the mode costs)."""

@@ -10,6 +10,7 @@ from tests.conftest import golden, blob_for, GOLDEN
 from totalsegmentator2d_amd import prng
 from totalsegmentator2d_amd.arch import UNetArch
 from totalsegmentator2d_amd.predictor import HIPnnUNetPredictor
+from tests.host_predictor import HostLogicPredictor
 
 pytestmark = pytest.mark.gpu
 
@@ -78,7 +79,7 @@ def test_device_aggregation_is_bit_identical_to_host_aggregation(name, order):
 
         def net(batch, fold):
             return engines[fold].forward(np.ascontiguousarray(batch))[0]
-        host = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, network=net, tile_dtype=order)
+        host = HostLogicPredictor(network=net, tile_step_size=step, use_mirroring=mirror is not None, tile_dtype=order)
         host.manual_initialization(arch, blobs, patch, inference_allowed_mirroring_axes=mirror)
         a = dev.predict_logits_from_preprocessed_data(data).cpu().numpy()
         b = host.predict_logits_from_preprocessed_data(data).cpu().numpy()

@@ -1,6 +1,6 @@
 """Host logic of the drop-in predictor on CPU: tiling, mirroring, fp16 Gaussian aggregation, fold ensemble.
-The network is injected (torch oracle) through the predictor's test hook, so no GPU is needed; the product path
-always builds HIP engines (tests/test_gpu_predictor.py)."""
+The network is injected (torch oracle) into tests/host_predictor.py's subclass of the predictor, so no GPU is needed; the product
+class has no such hook and always builds HIP engines (tests/test_gpu_predictor.py)."""
 import numpy as np
 import pytest
 
@@ -9,12 +9,13 @@ from tests.conftest import golden, blob_for
 from oracle import torch_oracle as O
 from totalsegmentator2d_amd import prng, weights
 from totalsegmentator2d_amd.predictor import HIPnnUNetPredictor
+from tests.host_predictor import HostLogicPredictor
 
 
 def _predictor(arch, sds, patch, step, mirror, order='float'):
     def net(batch, fold):   # row by row (B = 1) like upstream, so torch picks the same kernels as in the oracle run
         return np.concatenate([O.unet_forward(arch, sds[fold], batch[i:i + 1]).numpy() for i in range(batch.shape[0])])
-    p = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, network=net, tile_dtype=order)
+    p = HostLogicPredictor(network=net, tile_step_size=step, use_mirroring=mirror is not None, tile_dtype=order)
     p.manual_initialization(arch, [weights.pack_blob(arch, sd) for sd in sds], patch,
                             inference_allowed_mirroring_axes=mirror)
     return p
@@ -40,7 +41,7 @@ def test_predictor_duck_type_surface():
     arch = cases.unet(2, (32, 32), 2)
     sd = weights.synthetic_state_dict(arch, 3)
     p = _predictor(arch, [sd], (32, 32), 0.5, (0, 1))
-    assert 'nnUNetPredictor' in type(p).__name__                               # prediction_worker.py:103
+    assert 'nnUNetPredictor' in HIPnnUNetPredictor.__name__ and isinstance(p, HIPnnUNetPredictor)      # prediction_worker.py:103 (p: the tests' subclass of it)
     assert tuple(p.configuration_manager.patch_size) == (32, 32) and len(p.configuration_manager.spacing) == 2
     assert p.dataset_json['file_ending'] == '.nrrd' and len(p.dataset_json['channel_names']) == 2
     assert p.device.type == 'cuda' and p.verbose is False
@@ -66,7 +67,7 @@ def test_fp16_threshold_and_inf_predicates_match_the_float_definitions_exhaustiv
     definitions (sigmoid(float32(x)) > 0.5, isinf(x)) on every one of the 65536 half-precision values."""
     import torch
     from totalsegmentator2d_amd.export import convert_predicted_logits_to_segmentation_with_correct_shape
-    from totalsegmentator2d_amd.predictor import _any_inf_f16
+    from tests.host_predictor import _any_inf_f16
     v = np.arange(65536, dtype=np.uint32).astype(np.uint16)
     x = v.view(np.float16).reshape(1, 1, 256, 256)
     props = {'shape_before_cropping': (1, 256, 256), 'bbox_used_for_cropping': [[0, 1], [0, 256], [0, 256]]}
@@ -187,9 +188,9 @@ def test_blend_order_default_follows_the_precision_mode():
     """the fp32-parity modes blend like the reference's CPU path (the one BASELINE.json compares with), the 16-bit mode
     like its CUDA autocast path; an explicit tile_dtype wins."""
     net = lambda x: np.zeros((x.shape[0], 2) + x.shape[2:], np.float32)
-    assert HIPnnUNetPredictor(network=net).tile_dtype == 'float'
-    assert HIPnnUNetPredictor(network=net, precision='exact').tile_dtype == 'float'
-    assert HIPnnUNetPredictor(network=net, precision='f16').tile_dtype == 'half'
-    assert HIPnnUNetPredictor(network=net, precision='f16', tile_dtype='float').tile_dtype == 'float'
+    assert HostLogicPredictor(network=net).tile_dtype == 'float'
+    assert HostLogicPredictor(network=net, precision='exact').tile_dtype == 'float'
+    assert HostLogicPredictor(network=net, precision='f16').tile_dtype == 'half'
+    assert HostLogicPredictor(network=net, precision='f16', tile_dtype='float').tile_dtype == 'float'
     with pytest.raises(ValueError):
-        HIPnnUNetPredictor(network=net, tile_dtype='double')
+        HostLogicPredictor(network=net, tile_dtype='double')

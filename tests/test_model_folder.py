@@ -12,6 +12,7 @@ from tests import cases
 from totalsegmentator2d_amd import prng, weights
 from totalsegmentator2d_amd.arch import UNetArch
 from totalsegmentator2d_amd.predictor import HIPnnUNetPredictor
+from tests.host_predictor import HostLogicPredictor
 
 torch = pytest.importorskip('torch')
 
@@ -67,7 +68,7 @@ def _write_model_folder(root, arch, seeds, mirror, patch, module_prefix=False):
 def test_model_folder_is_read_like_upstream(tmp_path):
     arch, shape, patch, step, mirror, folds, seed = cases.SW_CASES['sw_folds_nomirror']
     blobs, labels = _write_model_folder(str(tmp_path), arch, [seed, seed + 1], (0, 1), patch, module_prefix=True)
-    p = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=False, network=lambda b: None)
+    p = HostLogicPredictor(network=None, tile_step_size=step, use_mirroring=False)
     p.initialize_from_trained_model_folder(str(tmp_path), None, 'checkpoint_final.pth')        # folds auto-discovered
     assert p.arch == arch
     assert len(p.list_of_parameters) == 2
@@ -78,14 +79,14 @@ def test_model_folder_is_read_like_upstream(tmp_path):
     assert p.dataset_json['labels'] == labels and p.dataset_json['multilabel'] is True
     assert p.plans_manager.transpose_forward == [0, 1, 2]
     # a single explicit fold, and a missing key is an error that names the key
-    q = HIPnnUNetPredictor(network=lambda b: None)
+    q = HostLogicPredictor(network=None)
     q.initialize_from_trained_model_folder(str(tmp_path), (1,), 'checkpoint_final.pth')
     assert len(q.list_of_parameters) == 1 and np.array_equal(q.list_of_parameters[0], blobs[1])
     ck = torch.load(os.path.join(str(tmp_path), 'fold_1', 'checkpoint_final.pth'), map_location='cpu', weights_only=False)
     del ck['network_weights']['decoder.transpconvs.0.weight']
     torch.save(ck, os.path.join(str(tmp_path), 'fold_1', 'checkpoint_final.pth'))
     with pytest.raises(KeyError, match='decoder.transpconvs.0.weight'):
-        HIPnnUNetPredictor(network=lambda b: None).initialize_from_trained_model_folder(str(tmp_path), (1,), 'checkpoint_final.pth')
+        HostLogicPredictor(network=None).initialize_from_trained_model_folder(str(tmp_path), (1,), 'checkpoint_final.pth')
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 """TS2D.predict() / Result.save() / ts2d CLI surface and the image utilities either side of the hot path, on CPU
-(the network is injected through the predictor's test hook; tests/test_gpu_surface.py runs the same surface on the engine).
+(the network is injected through tests/surface_util.py's subclass of the model; tests/test_gpu_surface.py runs the same surface on the engine).
 Counterparts of the reference's test_020/021/022/030 (which only assert types and file names)."""
 import os
 

@@ -35,6 +35,11 @@ using namespace ts2d;
 namespace {
 
 thread_local std::string g_err;
+// Generation counter of runs inside caller-provided (shared) workspaces: every such run stamps the workspace header with a fresh token
+// and remembers it; an engine whose token is no longer in the header knows that ANOTHER engine of the set has overwritten its
+// activations since (ts2d_engine_debug_tensor / ts2d_engine_check must not read them as its own - ADVICE r4).
+std::atomic<uint32_t> g_ws_generation{0};
+constexpr size_t kWsHeader = 256;         // bytes in front of the activation plan: [0] = token of the last run inside this memory
 
 int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -156,6 +161,7 @@ struct ts2d_engine {
     // workspace
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
     bool ws_external = false;     // d_ws is the caller's memory (ts2d_engine_set_workspace): shared by the engines of a sub-model set
+    uint32_t ws_token = 0;        // ... token this engine's last run wrote into its header (g_ws_generation)
     char* d_stage = nullptr; size_t stage_bytes = 0;      // host-buffer forwards only (ensure_staging)
     int ws_precision = -1; bool ws_keep = false;      // the activation plan of the workspace was made for this mode (composition depends on it)
     bool keep_activations = false;                    // ts2d_engine_set_keep_activations: one buffer per tensor (debug access, full diagnosis)
@@ -1115,7 +1121,8 @@ struct WsLayout { ActPlan plan; std::vector<size_t> o_sc, o_sh; size_t o_part = 
 WsLayout workspace_layout(const ts2d_engine* e, int B, int H, int W) {
     WsLayout L;
     L.plan = plan_activations(e, B, H, W, e->keep_activations);
-    size_t off = align_up(L.plan.bytes, 256);
+    for (size_t& o : L.plan.off) o += kWsHeader;          // (the header: owner token of a shared workspace)
+    size_t off = align_up(kWsHeader + L.plan.bytes, 256);
     L.o_sc.assign(e->tensors.size(), 0); L.o_sh.assign(e->tensors.size(), 0);
     for (size_t i = 0; i < e->tensors.size(); ++i) {
         const Tensor& t = e->tensors[i];
@@ -1224,8 +1231,24 @@ int workspace_release(ts2d_engine* e, hipStream_t st) {
 // clear_flags: first batch of a call.  The non-finite flag is cleared HERE, behind workspace_acquire: the previous run's head kernel
 // (possibly on another stream) sets it with atomicOr, and a memset issued before the stream is ordered behind that run could wipe
 // or pre-empt it.  ts2d_engine_predict_tiled clears it once per call, not per chunk, so an earlier chunk's inf / NaN survives.
+// Is the activation memory still this engine's?  Always for an allocation of its own; a shared workspace carries the token of the last
+// run of ANY engine inside it.  (Synchronises: debug / diagnosis paths only.)
+bool workspace_is_mine(ts2d_engine* e) {
+    if (!e->ws_external) return true;
+    if (!e->d_ws || !e->ws_token) return false;
+    if (e->ws_busy && hipEventSynchronize(e->ws_event) != hipSuccess) return false;
+    uint32_t tok = 0;
+    if (hipMemcpy(&tok, e->d_ws, sizeof(tok), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return tok == e->ws_token;
+}
+
 int run_forward(ts2d_engine* e, const float* d_in, int B, int H, int W, float* d_logits, uint32_t* d_mask, hipStream_t st, bool clear_flags = true) {
     TRY(workspace_acquire(e, st));
+    if (e->ws_external) {           // stamp the shared workspace: whatever another engine of the set left in it is gone after this run
+        e->ws_token = ++g_ws_generation;
+        if (!e->ws_token) e->ws_token = ++g_ws_generation;
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_ws), (int)e->ws_token, 1, st));
+    }
     if (clear_flags) HIP_TRY(hipMemsetAsync(e->d_flags, 0, 2 * sizeof(int), st));
     const int rc = run_forward_impl(e, d_in, B, H, W, d_logits, d_mask, st);
     const int rc2 = workspace_release(e, st);       // also after a failed launch: earlier kernels of the run may be in flight
@@ -1871,17 +1894,27 @@ int ts2d_engine_check(ts2d_engine* e) {
     if (e->last_input && has_nonfinite(e->last_input, (size_t)B * e->arch.input_channels * H * W, false) == 1) { where = "the network input"; input_bad = true; }
     float* d_copy = nullptr;
     const bool was_keep = e->keep_activations;
-    if (!input_bad && !was_keep && e->last_input) {
+    const bool mine = workspace_is_mine(e);        // a shared workspace may hold ANOTHER engine's activations by now: nothing in it is scanned then
+    if (!mine && !input_bad)
+        return fail(TS2D_ERR_INVALID, "non-finite logits (inf / NaN) in the last forward; its activations cannot be scanned for the first bad layer: the "
+                    "shared workspace (ts2d_engine_set_workspace) has been overwritten by another engine's run since - re-run this engine with a "
+                    "workspace of its own (ts2d_engine_set_workspace(e, NULL, 0)) to localise");
+    // (shared workspace: the diagnostic re-run with one buffer per tensor needs ~3x the memory the caller sized - skipped; the surviving
+    //  tensors of this engine's own last run are scanned below)
+    if (!input_bad && !was_keep && e->last_input && !e->ws_external) {
         // activations share buffers by liveness: most of the run has been overwritten.  The input of a synchronous call is still
         // there - run it once more with one buffer per tensor (slow path, taken only after an inf / NaN was flagged).
         const size_t nb = (size_t)B * e->arch.input_channels * H * W * sizeof(float);
         if (hipMalloc(reinterpret_cast<void**>(&d_copy), nb) == hipSuccess && hipMemcpy(d_copy, e->last_input, nb, hipMemcpyDeviceToDevice) == hipSuccess) {
             e->keep_activations = true;
+            const bool was_fuse0 = e->use_fuse0;
+            e->use_fuse0 = false;             // (the first block as its own kernel: its output can be scanned and named)
             hipStream_t st = e->last_stream ? e->last_stream : e->stream;
             const bool prof = e->profiling; e->profiling = false;
             if (ensure_workspace(e, B, H, W) != TS2D_OK || run_forward(e, d_copy, B, H, W, nullptr, nullptr, st, false) != TS2D_OK ||
                 hipStreamSynchronize(st) != hipSuccess) { /* keep the generic message */ }
             e->profiling = prof;
+            e->use_fuse0 = was_fuse0;
             e->last_input = nullptr;
         }
     }
@@ -2052,7 +2085,11 @@ int ts2d_engine_op_times(ts2d_engine* e, float* ms, int n_ops) {
 int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_t capacity, int32_t dims[4]) {
     if (!e || !name || !out || !dims) return fail(TS2D_ERR_INVALID, "ts2d_engine_debug_tensor: null argument");
     const int ti = tensor_index(e, name);
-    if (ti < 0 || !e->lastB) return fail(TS2D_ERR_INVALID, "no tensor '%s' (or no forward has run)", name);
+    if (ti < 0) return fail(TS2D_ERR_INVALID, "no tensor '%s'", name);
+    if (!e->lastB) return fail(TS2D_ERR_STATE, "no forward has run on this engine (or its workspace was replaced since): nothing to read for '%s'", name);
+    if (!workspace_is_mine(e))
+        return fail(TS2D_ERR_STATE, "tensor '%s': the shared workspace (ts2d_engine_set_workspace) has been overwritten by another engine's forward "
+                    "since this engine's last run - run this engine last, or give it a workspace of its own", name);
     const Tensor& t = e->tensors[ti];
     if (t.data && !t.resident)
         return fail(TS2D_ERR_STATE, "tensor '%s' was overwritten by a later activation of the same run (buffers are shared by liveness): "

@@ -48,6 +48,7 @@ class Engine:
         self._auto_keep = False      # ... or by debug_tensor, until the next forward (which returns to the shared arena)
         self._last = None            # (weak reference to the input, logits?, mask?) of the last forward: debug_tensor re-runs it with
                                      # private buffers.  Weak: a production call must not pin the caller's batch in HBM.
+        self._ran = False            # a forward has run on this handle (distinguishes "no forward yet" from "its input is gone")
         self._h = ctypes.c_void_p()
         d = _desc(arch)
         if blob is not None:
@@ -139,6 +140,7 @@ class Engine:
         if self._auto_keep and not _debug_rerun:      # debug_tensor left private buffers behind: a production call returns to the shared arena
             _lib.check(self.lib.ts2d_engine_set_keep_activations(self._h, 0), 'ts2d_engine_set_keep_activations')
             self._auto_keep = False
+        self._ran = True
         try:
             self._last = (weakref.ref(x), logits, mask)
         except TypeError:
@@ -247,12 +249,19 @@ class Engine:
 
     def debug_tensor(self, name: str, capacity: int = 1 << 26) -> np.ndarray:
         """Test accessor: activation `name` of the last forward as torch would hold it (NCHW, norm+act applied).  Activations
-        share buffers by liveness: the first call switches the engine to private buffers and runs the last forward again."""
+        share buffers by liveness: the first call switches the engine to private buffers and runs the last forward again - on the
+        SAME input object, which the engine holds only weakly: keep a reference to the array / tensor you passed to forward()
+        (``e.forward(x[None])`` or ``e.forward(a.astype(np.float32))`` leave nothing to re-run), or call ``keep_activations(True)``
+        before the forward.  With the first block fused into the second (split mode) ``enc0.c0`` is not materialised: create the
+        engine with ``options={'fuse0': 0}`` to read it."""
         if not (self._keep or self._auto_keep):
+            if not self._ran:
+                raise RuntimeError("debug_tensor: no forward has run on this engine")
             x = self._last[0]() if self._last is not None else None
             if x is None:
-                raise RuntimeError("debug_tensor: the input of the last forward is gone (the engine holds it weakly) - keep a "
-                                   "reference to it, or call keep_activations(True) before the forward")
+                raise RuntimeError("debug_tensor: the input of the last forward has been garbage-collected (the engine holds it weakly so "
+                                   "that a production call does not pin the batch): keep a reference to the object passed to forward(), "
+                                   "or call keep_activations(True) before the forward")
             _lib.check(self.lib.ts2d_engine_set_keep_activations(self._h, 1), 'ts2d_engine_set_keep_activations')
             self._auto_keep = True
             self.forward(x, logits=self._last[1], mask=self._last[2], _debug_rerun=True)
@@ -268,7 +277,8 @@ class Engine:
 
     def materialised(self, name: str) -> bool:
         """Test accessor: False if the last forward composed the op that produces `name` into its consumer (a transposed conv
-        folded into the next block, ``csrc/kernels_upc.h``), so that the tensor was never written."""
+        folded into the next block, ``csrc/kernels_upc.h``; the first block recomputed inside the second), so that the tensor was
+        never written.  Like :meth:`debug_tensor` it re-runs the last forward: keep a reference to its input."""
         try:
             self.debug_tensor(name)
             return True

@@ -90,9 +90,7 @@ class HIPModel:
         kw['verbose'] = bool(p.get('nnu.verbose', False))
         kw['device'] = self._config.get('device')
         kw['precision'] = p.get('hip.precision', self._config.get('precision', 'split'))     # engine arithmetic mode (include/ts2d_engine.h)
-        if self._config.get('network') is not None:          # test hook: host-logic tests without a GPU (predictor.py)
-            kw['network'] = self._config['network']
-        pred = HIPnnUNetPredictor(**kw)
+        pred = self._make_predictor(kw)
         syn = self._config.get('synthetic')
         if syn is not None:
             pred.manual_initialization(syn['arch'], syn['blobs'], syn['patch_size'], syn.get('spacing', (1.5, 1.5)),
@@ -103,6 +101,10 @@ class HIPModel:
         self._predictor = pred
         if wait:
             self.await_startup()
+
+    def _make_predictor(self, kw: dict):
+        """The predictor object behind this model: always the HIP one (the CPU surface tests subclass the model, tests/surface_util.py)."""
+        return HIPnnUNetPredictor(**kw)
 
     def await_startup(self):
         """Warm-up on a zero patch (reference prediction_worker.py:74-96): allocates the workspace, loads the kernels."""

@@ -38,28 +38,19 @@ class _Device:
         return f"device(type='cuda', index={self.index})"
 
 
-def _any_inf_f16(x: np.ndarray) -> bool:
-    """np.any(np.isinf(x)) for float16 arrays on the bit pattern (exponent all ones, mantissa zero): numpy's float16
-    isinf converts element-wise and costs ~10 ms on an 18x644x512 logits array; this is the same predicate."""
-    if x.dtype != np.float16:
-        return bool(np.any(np.isinf(x)))
-    v = np.ascontiguousarray(x).view(np.uint16)
-    return bool(np.any((v & np.uint16(0x7FFF)) == np.uint16(0x7C00)))
-
-
 class HIPnnUNetPredictor:
     def __init__(self, tile_step_size: float = 0.5, use_gaussian: bool = True, use_mirroring: bool = True,
                  perform_everything_on_device: bool = True, device=None, verbose: bool = False,
                  verbose_preprocessing: bool = False, allow_tqdm: bool = True, max_batch: int = 64, precision: str = 'split',
-                 tile_dtype: Optional[str] = None, network: Optional[Callable[[np.ndarray], np.ndarray]] = None):
+                 tile_dtype: Optional[str] = None):
         """``tile_dtype``: dtype of a tile prediction when it is blended into upstream's float16 buffers - 'float' (the
         reference's CPU path, taken when ``torch.cuda.is_available()`` is false, ``nnu.py:161-163``: fp32 tile x half gaussian in
         fp32, ONE rounding per ``logits[sl] += p``) or 'half' (the reference's CUDA path under fp16 autocast: the tile is half, the
         product and the sum each round to half).  Default (None): the blend order of the reference path the chosen arithmetic
         mirrors - 'float' for the fp32-parity modes ('split', 'exact': BASELINE.json compares with the CPU path), 'half' for
         ``precision='f16'`` (the autocast-like mode).
-        ``network``: test hook - a callable [B,C,h,w] -> [B,K,h,w] used INSTEAD of creating HIP engines (host-logic
-        unit tests on machines without a GPU).  The product path never passes it."""
+        (The network is always the HIP engine: the numpy restatement of the tiling / aggregation that the CPU tests use lives in
+        tests/host_predictor.py, a subclass - nothing in this module can route around the engine.)"""
         self.tile_step_size = tile_step_size
         self.use_gaussian = use_gaussian
         self.use_mirroring = use_mirroring
@@ -83,7 +74,6 @@ class HIPnnUNetPredictor:
             if getattr(device, 'type', 'cuda') != 'cuda':
                 raise RuntimeError("HIPnnUNetPredictor runs on an MI355X only; there is no CPU fallback")
         self.device = _Device(idx)
-        self._network_override = network
         self.engines: list = []
         self.arch: Optional[UNetArch] = None
         self.plans_manager = None
@@ -147,8 +137,6 @@ class HIPnnUNetPredictor:
         self.configuration_manager.use_mask_for_norm = cfg.get('use_mask_for_norm', self.configuration_manager.use_mask_for_norm)
 
     def _create_engines(self):
-        if self._network_override is not None:
-            return
         from .engine import Engine            # raises loudly if libts2d_engine.so is missing - no fallback
         for e in self.engines:
             e.close()
@@ -163,16 +151,6 @@ class HIPnnUNetPredictor:
         self.engines = []
 
     # ------------------------------------------------------------------ inference
-    def _run_network(self, fold: int, batch: np.ndarray) -> np.ndarray:
-        if self._network_override is not None:
-            return np.asarray(self._network_override(batch, fold) if self._network_override.__code__.co_argcount > 1
-                              else self._network_override(batch), dtype=np.float32)
-        out = []
-        for a in range(0, batch.shape[0], self.max_batch):
-            lg, _ = self.engines[fold].forward(batch[a:a + self.max_batch], logits=True, mask=False)
-            out.append(lg)
-        return out[0] if len(out) == 1 else np.concatenate(out, 0)
-
     def predict_sliding_window_return_logits(self, data: np.ndarray, fold: int = 0) -> np.ndarray:
         """One fold: tiles x mirror variants -> one engine batch -> upstream's fp16 Gaussian aggregation.
         data [C,Z,H,W] float32 -> float16 [K,Z,H,W]."""
@@ -183,58 +161,23 @@ class HIPnnUNetPredictor:
         padded, revert = sw.pad_nd_image(data, patch)
         C, Z, H, W = padded.shape
         slicers = sw.tile_slicers((H, W), patch, self.tile_step_size, Z)
-        combos = sw.mirror_combos(self.allowed_mirroring_axes if self.use_mirroring else None)
         if self.use_mirroring and self.allowed_mirroring_axes and max(self.allowed_mirroring_axes) > 1:
             raise AssertionError('mirror_axes does not match the dimension of the input!')
-        nv = len(combos)
-        if self._network_override is None:
-            # product path: gather (with mirroring), network, mirror-average and fp16 Gaussian aggregation all on the device
-            g = sw.compute_gaussian(patch) if self.use_gaussian else None
-            K = self.arch.num_classes
-            logits = np.empty((K, Z, H, W), dtype=np.float16)
-            axes = self.allowed_mirroring_axes if self.use_mirroring else None
-            any_inf = False
-            for d in range(Z):
-                tiles = [(sx, sy) for (dd, sx, sy) in slicers if dd == d]
-                # (Z == 1, the 2-D case: logits[:, d] is contiguous and the engine writes into it directly)
-                out16, _ = self.engines[fold].predict_tiled(padded[:, d], patch, tiles, axes, g, want_logits=True,
-                                                            out_logits=logits[:, d] if Z == 1 else None)
-                if Z != 1:
-                    logits[:, d] = out16
-                any_inf = any_inf or self.engines[fold].last_tiled_inf
-            if any_inf:
-                raise RuntimeError('Encountered inf in predicted array. Aborting... If this problem persists, reduce '
-                                   'value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits to fp32')
-            return logits[(slice(None),) + revert[1:]]
-        batch = np.empty((len(slicers) * nv, C, patch[0], patch[1]), dtype=np.float32)
-        for t, (d, sx, sy) in enumerate(slicers):
-            x = padded[:, d, sx:sx + patch[0], sy:sy + patch[1]]
-            for v, c in enumerate(combos):
-                batch[t * nv + v] = np.flip(x, [a - 1 for a in c]) if c else x      # tensor dim a of [1,C,h,w] = dim a-1 here
-        y = self._run_network(fold, batch)
-        K = y.shape[1]
-        g = sw.compute_gaussian(patch) if self.use_gaussian else np.ones(patch, dtype=np.float16)
-        logits = np.zeros((K, Z, H, W), dtype=np.float16)
-        n_pred = np.zeros((Z, H, W), dtype=np.float16)
-        for t, (d, sx, sy) in enumerate(slicers):
-            p = y[t * nv].copy()
-            for v in range(1, nv):
-                p += np.flip(y[t * nv + v], [a - 1 for a in combos[v]])
-            if nv > 1:
-                p /= np.float32(nv)
-            sl = (slice(None), d, slice(sx, sx + patch[0]), slice(sy, sy + patch[1]))
-            if self.tile_dtype == 'half':          # CUDA autocast order: half tile, half product, half sum (three roundings)
-                p = p.astype(np.float16)
-                if self.use_gaussian:
-                    p = p * g
-                logits[sl] += p
-            else:                                  # reference CPU path: fp32 tile * float(g) in fp32, ONE rounding into the half buffer
-                if self.use_gaussian:
-                    p = p * g.astype(np.float32)
-                logits[sl] = (logits[sl].astype(np.float32) + p).astype(np.float16)
-            n_pred[d, sx:sx + patch[0], sy:sy + patch[1]] += g
-        logits = logits / n_pred
-        if _any_inf_f16(logits):
+        # gather (with mirroring), network, mirror-average and fp16 Gaussian aggregation all on the device
+        g = sw.compute_gaussian(patch) if self.use_gaussian else None
+        K = self.arch.num_classes
+        logits = np.empty((K, Z, H, W), dtype=np.float16)
+        axes = self.allowed_mirroring_axes if self.use_mirroring else None
+        any_inf = False
+        for d in range(Z):
+            tiles = [(sx, sy) for (dd, sx, sy) in slicers if dd == d]
+            # (Z == 1, the 2-D case: logits[:, d] is contiguous and the engine writes into it directly)
+            out16, _ = self.engines[fold].predict_tiled(padded[:, d], patch, tiles, axes, g, want_logits=True,
+                                                        out_logits=logits[:, d] if Z == 1 else None)
+            if Z != 1:
+                logits[:, d] = out16
+            any_inf = any_inf or self.engines[fold].last_tiled_inf
+        if any_inf:
             raise RuntimeError('Encountered inf in predicted array. Aborting... If this problem persists, reduce '
                                'value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits to fp32')
         return logits[(slice(None),) + revert[1:]]

@@ -57,8 +57,8 @@ class TS2D:
                 raise RuntimeError(f"Failed to load model {mid}") from ex
         for model in self.models.values():
             model.await_startup()
-        # GPU projection only on the product path (models backed by HIP engines, not by the CPU test hook)
-        self._gpu_projection = all(m._config.get('network') is None for m in self.models.values())
+        # the projections run on the GPU when every model is backed by HIP engines (always, on the product path)
+        self._gpu_projection = all(bool(getattr(getattr(m, '_predictor', None), 'engines', None)) for m in self.models.values())
 
     def __enter__(self):
         return self
