@@ -35,6 +35,31 @@ def test_predict_matches_oracle_pipeline(asset, collapse, tmp_path):
         assert nrrd.read(os.path.join(str(tmp_path), 'case.seg.nrrd')).components == 7
 
 
+def test_concurrent_sub_models_equal_the_serial_order():
+    """TS2D.predict drives the sub-models of a case concurrently (one host thread and one HIP stream per engine; the reference drives
+    them one after the other, ts2d/tool.py:110-112): the merged segmentation, every per-model segmentation and the metadata must be
+    identical to the serial order, on the 3-D sample (GPU projection + device z-score shared by the sub-models) and on a 2-D one."""
+    ids = ('ts2d-v2-ep4000b2_cardiac', 'ts2d-v2-ep4000b2_muscles', 'ts2d-v2-ep4000b2_ribs')
+    models = {m: synthetic_model(m, 3 + 2 * i, 41 + i, patch=(64, 64), mirror=True)[0] for i, m in enumerate(ids)}
+    with TS2D(models=models) as ts:
+        for asset in ('sample_s0521.nrrd', 'sample_s0616.nrrd'):
+            ts.concurrent_models = True
+            a = ts.predict(os.path.join(A, asset))
+            a2 = ts.predict(os.path.join(A, asset))
+            ts.concurrent_models = False
+            b = ts.predict(os.path.join(A, asset))
+            assert a.models == b.models == sorted(ids)
+            assert np.array_equal(a.get_segmentation().array, b.get_segmentation().array) and a.get_segmentation().meta == b.get_segmentation().meta
+            assert np.array_equal(a.get_segmentation().array, a2.get_segmentation().array)
+            for m in ids:
+                assert np.array_equal(a.get_segmentation(m).array, b.get_segmentation(m).array)
+                t = a.data['models'][m]['timestamps']
+                assert t['start'] <= t['preprocessed'] <= t['predicted'] <= t['exported']
+            # concurrent: the prediction stages of the sub-models overlap in time
+            ta = [a.data['models'][m]['timestamps'] for m in ids]
+            assert max(t['preprocessed'] for t in ta) < min(t['predicted'] for t in ta) or len(ids) == 1
+
+
 def test_gpu_projection_equals_oracle_projection():
     """ts2d_project_coronal (strided view, no reorientation copy) against oracle/input_oracle.py (DICOMOrient 'RAI' + ITK max /
     mean projection + Float32 cast; the mean is real-valued, pinned by the reference's assets in tests/test_oracle.py): bit for

@@ -2,9 +2,11 @@
 
 Same constructor, ``predict(input, collapse, merge) -> TS2D.Result`` and ``Result`` accessors / ``save`` naming
 (``<name>.seg.nrrd``, ``<name>-<group>.seg.nrrd``, ``<name>_<channel>.nrrd``; reference tool.py:235-311,
-test/test_030_cli.py:46-50).  Differences: models run in-process (no worker pool, no temp files), sub-models are still
-driven one after the other (reference tool.py:110-112), PNG visualisation is not implemented (``content='visual'`` is
-skipped with a warning; SURVEY.md marks rendering out of scope).
+test/test_030_cli.py:46-50).  Differences: models run in-process (no worker pool, no temp files); the sub-models of one case
+run CONCURRENTLY (one host thread per sub-model, each engine on its own HIP stream: a case is 2 tiles x 4 mirror passes = 8 slices
+per sub-model, which leaves most of the GPU idle when the five are driven one after the other as the reference does,
+tool.py:110-112; ``concurrent_models=False`` restores that order - the results are identical); PNG visualisation is not
+implemented (``content='visual'`` is skipped with a warning; SURVEY.md marks rendering out of scope).
 """
 from __future__ import annotations
 
@@ -27,10 +29,12 @@ def _as_list(v):
 
 class TS2D:
     def __init__(self, key: str = "ts2d", use_remote: bool = True, fetch_remote: bool = True,
-                 models: Optional[Dict[str, HIPModel]] = None, zoo_root: Optional[str] = None, device=None):
+                 models: Optional[Dict[str, HIPModel]] = None, zoo_root: Optional[str] = None, device=None,
+                 concurrent_models: bool = True):
         """``models``: pre-built ``{id: HIPModel}`` (synthetic-weight models in tests / bench); otherwise `key` is resolved
         against the local zoo.  ``use_remote`` / ``fetch_remote`` are accepted for signature compatibility (no network)."""
         self.models: Dict[str, HIPModel] = {}
+        self.concurrent_models = bool(concurrent_models)
         if models is None:
             self.zoo = LocalZoo(zoo_root)
             ids = self.zoo.resolve(key, unique_model=True)
@@ -78,8 +82,20 @@ class TS2D:
             raise RuntimeError(f"input must be a string path or an image, found: {type(input).__name__}")
         result: dict = {}
         cache: dict = {}
-        for mid in sorted(self.models):
-            result.setdefault('models', {})[mid] = self._predict_model(mid, input, collapse, cache)
+        order = sorted(self.models)
+        # input side per sub-model (projections are computed once and cached), then the networks - concurrently: the C-ABI's handles
+        # are independent (include/ts2d_engine.h: one caller thread per engine), every engine runs on its own stream, and ctypes
+        # releases the interpreter lock for the duration of a call
+        prepared = {mid: self._prepare_model_input(mid, input, cache) for mid in order}
+        if self.concurrent_models and len(order) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=len(order)) as pool:
+                futs = {mid: pool.submit(self._apply_model, mid, prepared[mid], collapse) for mid in order}
+                done = {mid: f.result() for mid, f in futs.items()}      # (the first failure is raised, in sub-model order)
+        else:
+            done = {mid: self._apply_model(mid, prepared[mid], collapse) for mid in order}
+        for mid in order:
+            result.setdefault('models', {})[mid] = done[mid]
         if merge:
             segs = [r['segmentation'] for _, r in sorted(result['models'].items())]
             result['segmentation'] = segs[0] if len(segs) == 1 else combine_segmentations(segs)
@@ -89,9 +105,11 @@ class TS2D:
         return TS2D.Result(result)
 
     def _predict_model(self, mid: str, input: nrrd.Image, collapse: bool, cache: dict) -> dict:
+        return self._apply_model(mid, self._prepare_model_input(mid, input, cache), collapse)
+
+    def _prepare_model_input(self, mid: str, input: nrrd.Image, cache: dict):
+        """Reference tool.py:145-171: the 2-D multi-channel input of one sub-model (projections cached across sub-models)."""
         model = self.models[mid]
-        res = {'id': mid, 'revision': model.revision}
-        res['model'], res['group'] = decompose_model_key(mid)
         channels = sorted(model.channels.items())
         projections = cache.setdefault('projections', {})
         if get_actual_dimension(input) > 2:
@@ -123,6 +141,14 @@ class TS2D:
         if dz is not None and not native_2d and all(n.lower() in ('max', 'mip', 'mean', 'avg') for _, n in channels):
             # channel order of THIS model over the (max, mean) planes the device normalised
             input2d.device_zscore = dict(dz, order=tuple(0 if n.lower() in ('max', 'mip') else 1 for _, n in channels))
+        return input, input2d, native_2d
+
+    def _apply_model(self, mid: str, prepared, collapse: bool) -> dict:
+        """Reference tool.py:172-174: ``model.apply`` + restoring the 3-D geometry."""
+        model = self.models[mid]
+        input, input2d, native_2d = prepared
+        res = {'id': mid, 'revision': model.revision}
+        res['model'], res['group'] = decompose_model_key(mid)
         seg = model.apply(input2d)
         if not (collapse or native_2d):
             seg = restore_dimension(seg, input)
