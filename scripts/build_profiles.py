@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'scripts'))
 from pmc_traffic import short  # noqa: E402
 
+FORWARDS = 13          # scripts/collect_profiles.sh: --steps 10 --warmup 3
 NAMES = ['SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_LDS_IDX_ACTIVE', 'SQ_LDS_BANK_CONFLICT', 'SQ_ACTIVE_INST_ANY',
          'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY']
 
@@ -21,8 +22,8 @@ def sq_table(path, tag):
         k = short(r['Kernel_Name']); agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Counter_Name'] == 'SQ_BUSY_CYCLES':
             disp[k] += 1
-    out = ['# rocprofv3 --kernel-trace --pmc ' + ' '.join(NAMES) + ' -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-modes --no-profile',
-           f'# {tag}, final kernel sources (B=64 2x512x512, split mode); sums over the 3 forwards of the run; kernel labels as ts2d_engine_op_kernel',
+    out = ['# rocprofv3 --kernel-trace --pmc ' + ' '.join(NAMES) + ' -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes --no-profile',
+           f'# {tag}, final kernel sources (B=64 2x512x512, split mode); sums over the 13 forwards of the run; kernel labels as ts2d_engine_op_kernel',
            '# derived: mfma/busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (summed over the SIMDs of a shader engine: 32 = every matrix pipe busy all the time);',
            '#          lds_conflict% = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE;  lds/busy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CYCLES (8 = every CU of the SE indexing LDS all the time)',
            '%-28s %5s %12s %12s %12s %12s %12s %9s %13s %8s' % ('kernel', 'disp', 'busy', 'wave_cyc', 'mfma_busy', 'lds_active', 'lds_conflict', 'mfma/busy', 'lds_conflict%', 'lds/busy')]
@@ -43,13 +44,13 @@ def main():
     f16 = os.path.join(src, 'prof_kt_f16', 'runc_kernel_stats.csv')
     if os.path.exists(f16):
         with open(os.path.join(P, f'{tag}_kernel_stats_f16.csv'), 'w') as f:
-            f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --precision f16 --steps 2 --warmup 1 --no-cpu-baseline --no-other-modes --no-profile (3 forwards)\n')
+            f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --precision f16 --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes --no-profile (13 forwards)\n')
             f.write(open(f16).read())
     hp = os.path.join(src, 'hbm_probe.txt')
     if os.path.exists(hp):
         shutil.copy(hp, os.path.join(P, f'{tag}_hbm_probe.txt'))
     pj = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'pmc_traffic.py'), os.path.join(src, 'pmc_fetch', 'runc_counter_collection.csv'),
-                         os.path.join(src, 'pmc_write', 'runc_counter_collection.csv'), '3', os.path.join(src, 'prof_kt', 'runc_kernel_stats.csv')],
+                         os.path.join(src, 'pmc_write', 'runc_counter_collection.csv'), str(FORWARDS), os.path.join(src, 'prof_kt', 'runc_kernel_stats.csv')],
                         check=True, capture_output=True, text=True).stdout
     for name in ('pmc_traffic.json', f'{tag}_pmc_traffic.json'):
         open(os.path.join(P, name), 'w').write(pj)
