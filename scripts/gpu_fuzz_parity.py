@@ -12,7 +12,43 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 worst = {'split': 0.0, 'exact': 0.0}
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 big = len(sys.argv) > 3 and sys.argv[3] == 'big'      # larger extents / wider nets: the 512-thread kernels (conv3x3_f16x3_q, conv3x3_upq), composed blocks
+geo = len(sys.argv) > 3 and sys.argv[3] == 'geo'      # round 5: per-axis strides, extents that are multiples of the strides only (extent-following tiles,
+                                                      # composed blocks on them, whole small images per tile at any extent)
 for t in range(n):
+    if geo:
+        ns = int(rng.integers(3, 7))
+        feats = [32]
+        for i in range(1, ns): feats.append(min(feats[-1] * 2, 256))
+        strides = [(1, 1)]
+        for i in range(1, ns):
+            strides.append((2, 2) if (i < ns - 2 or rng.random() < 0.6) else [(2, 1), (1, 2), (2, 2)][int(rng.integers(0, 3))])
+        arch = cases.unet(ns, feats, int(rng.integers(1, 27)), cin=int(rng.integers(1, 3)), nconv=int(rng.integers(1, 3)), strides=strides)
+        dy, dx = arch.divisors
+        H = dy * int(rng.integers(1, max(2, 288 // dy) + 1)); W = dx * int(rng.integers(1, max(2, 288 // dx) + 1))
+        while (H // dy) * (W // dx) < 4: W += dx
+        B = int(rng.integers(1, 4))
+        sd = weights.synthetic_state_dict(arch, 700 + t); blob = weights.pack_blob(arch, sd)
+        x = prng.normal_f32(800 + t, 1, (B, arch.input_channels, H, W))
+        ref = O.unet_forward(arch, sd, x).numpy()
+        ref16 = O.unet_forward(arch, sd, x, emulate='f16').numpy()
+        with Engine(arch, blob) as e:
+            line = f'{t:2d} geo stages={ns} strides_tail={strides[-2:]} feats={feats} K={arch.num_classes} cin={arch.input_channels} B={B} {H}x{W}:'
+            for mode in ('split', 'exact', 'f16'):
+                e.set_precision(mode)
+                e.set_profiling(True)
+                lg, mk = e.forward(x, logits=True, mask=(W % 32 == 0))
+                kern = sorted(set(e.op_kernels().values()) - {'finalize_stats'})
+                e.set_profiling(False)
+                err = float(np.abs(lg - (ref16 if mode == 'f16' else ref)).max())
+                assert err <= (0.2 if mode == 'f16' else 1e-4), (line, mode, err)
+                if mode != 'f16': worst[mode] = max(worst[mode], err)
+                if mk is not None:
+                    assert np.array_equal(unpack_mask(mk, W), (lg > np.float32(1.5 * 2.0 ** -24)).astype(np.uint8)), (line, mode, 'mask')
+                line += f' {mode} {err:.2e}'
+                if mode == 'split':
+                    line += ' [' + ' '.join(k.replace('conv3x3', 'c') for k in kern) + ']'
+            print(line, flush=True)
+        continue
     if big:
         ns = int(rng.integers(3, 5))
         feats = [int(rng.choice([32, 64]))]

@@ -603,6 +603,40 @@ def test_randomised_shapes_against_the_torch_oracle():
                     assert np.array_equal(unpack_mask(mk, W), _oracle_mask(lg)), (t, mode)
 
 
+def test_randomised_strides_and_extents_against_the_torch_oracle():
+    """A fixed-seed slice of `scripts/gpu_fuzz_parity.py <seed> <n> geo` (round 5): random per-axis strides in the last stages, extents
+    that are multiples of the strides only - extent-following tiles, composed blocks on them, whole small images per tile at any
+    extent, the generic kernel for anisotropic stages - all three modes against the oracles."""
+    from oracle import torch_oracle as O
+    from totalsegmentator2d_amd import weights, prng
+    rng = np.random.default_rng(11)
+    for t in range(8):
+        ns = int(rng.integers(3, 7))
+        feats = [32]
+        for i in range(1, ns):
+            feats.append(min(feats[-1] * 2, 256))
+        strides = [(1, 1)]
+        for i in range(1, ns):
+            strides.append((2, 2) if (i < ns - 2 or rng.random() < 0.6) else [(2, 1), (1, 2), (2, 2)][int(rng.integers(0, 3))])
+        arch = cases.unet(ns, feats, int(rng.integers(1, 27)), cin=int(rng.integers(1, 3)), nconv=int(rng.integers(1, 3)), strides=strides)
+        dy, dx = arch.divisors
+        H = dy * int(rng.integers(1, max(2, 288 // dy) + 1)); W = dx * int(rng.integers(1, max(2, 288 // dx) + 1))
+        while (H // dy) * (W // dx) < 4:
+            W += dx
+        B = int(rng.integers(1, 4))
+        sd = weights.synthetic_state_dict(arch, 700 + t)
+        x = prng.normal_f32(800 + t, 1, (B, arch.input_channels, H, W))
+        ref = O.unet_forward(arch, sd, x).numpy()
+        ref16 = O.unet_forward(arch, sd, x, emulate='f16').numpy()
+        with Engine(arch, weights.pack_blob(arch, sd)) as e:
+            for mode, tol, want in (('split', TOL, ref), ('exact', TOL, ref), ('f16', 0.2, ref16)):
+                e.set_precision(mode)
+                lg, mk = e.forward(x, logits=True, mask=(W % 32 == 0))
+                assert np.abs(lg - want).max() <= tol, (t, mode, feats, strides, B, H, W, float(np.abs(lg - want).max()))
+                if mk is not None:
+                    assert np.array_equal(unpack_mask(mk, W), _oracle_mask(lg)), (t, mode)
+
+
 def test_short_wide_images_get_one_image_per_tile():
     """Regression (found by scripts/gpu_fuzz_parity.py): at a level where the image is shorter than 8 rows but wider than 32
     columns (8x120 input, 4 stages -> 4x60, 2x30, 1x15) a tile of TH x 32 < 256 pixels must still hold ONE image."""
