@@ -118,6 +118,24 @@ inline hipError_t allow_max_lds(const void* kern, std::atomic<uint64_t>& done) {
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Pixel tiling of one level: tile = NIMG images x TH x TW pixels, NIMG * TH * TW <= 256 (a workgroup's 256 GEMM rows).
+struct TileGeom { int TH, TW, NIMG, lgTH, lgTW, tiles_x, tiles_y, n_mtiles, PH, PW; };
+
+enum Kern { K_NONE = 0, K_FUSED_AWAY, K_FIRST, K_FIRST_STATS, K_EXACT, K_S1_GENERIC, K_S1_ONE, K_S1_QP, K_S1_H32, K_S1_H2, K_S1_RES32, K_S1_RES32F,
+            K_S2_V2, K_S2_ONE, K_S2_GENERIC, K_T_ONE, K_T_GENERIC, K_UP0, K_UPQ, K_UPC, K_UPC_H, K_UPC_H2, K_HEAD_MFMA, K_HEAD_1X1 };
+
+struct Choice {
+    Kern k = K_NONE;
+    TileGeom g{};               // the pixel tiling the kernel walks
+    int bn = 0;                 // output columns per workgroup
+    int ksplit = 1;
+    bool fused_stats = false;   // per-tile partial statistics come out of the kernel's epilogue (else stats_direct / splitk_reduce_stats)
+    bool first_full = false;    // (K_FIRST*) complete one-image 256-pixel tiles: the persistent variant
+    bool flex = false;          // (K_UPC / K_UPC_H) the level is no multiple of 8 x 32: the FLEX instance on the extent-following tile c.g
+};
+
+
 inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -162,6 +180,9 @@ struct ts2d_engine {
     char* d_ws = nullptr; size_t ws_bytes = 0; int wsB = 0, wsH = 0, wsW = 0;
     bool ws_external = false;     // d_ws is the caller's memory (ts2d_engine_set_workspace): shared by the engines of a sub-model set
     uint32_t ws_token = 0;        // ... token this engine's last run wrote into its header (g_ws_generation)
+    // the kernel choices of the last (B, H, W, precision, options): a forward of the same shape does not search tile shapes again
+    // (62 launches per forward: at B = 1 the host side is a visible part of the 2.5 ms)
+    std::vector<Choice> plan; int planB = 0, planH = 0, planW = 0, plan_prec = -1; unsigned plan_gen = 0, opt_gen = 1;
     char* d_stage = nullptr; size_t stage_bytes = 0;      // host-buffer forwards only (ensure_staging)
     int ws_precision = -1; bool ws_keep = false;      // the activation plan of the workspace was made for this mode (composition depends on it)
     bool keep_activations = false;                    // ts2d_engine_set_keep_activations: one buffer per tensor (debug access, full diagnosis)
@@ -618,8 +639,6 @@ int upload_weights(ts2d_engine* e, const float* blob, size_t n_floats) {
 inline int ct_total(const Op& op) { return op.cin + op.cin_skip; }
 inline int lg_exact(int v) { return (v > 0 && (v & (v - 1)) == 0) ? ilog2(v) : -1; }
 
-// Pixel tiling of one level: tile = NIMG images x TH x TW pixels, NIMG * TH * TW <= 256 (a workgroup's 256 GEMM rows).
-struct TileGeom { int TH, TW, NIMG, lgTH, lgTW, tiles_x, tiles_y, n_mtiles, PH, PW; };
 
 inline void tile_finish(TileGeom& g, int B, int Ht, int Wt, int sy, int sx, int taps) {
     const bool p2 = lg_exact(g.TH) >= 0 && lg_exact(g.TW) >= 0;
@@ -863,19 +882,6 @@ int choose_ksplit(const Op& op, const TileGeom& g) {
 // ONE function decides which kernel serves an op for (precision, options, B, H, W).  The activation plan (which tensors exist), the
 // workspace sizing and the run (what is launched) all ask it, so they cannot disagree (the eligibility tests
 // used to be written at plan time and again inline at launch; round 3's plan / run mismatch came from exactly that).
-enum Kern { K_NONE = 0, K_FUSED_AWAY, K_FIRST, K_FIRST_STATS, K_EXACT, K_S1_GENERIC, K_S1_ONE, K_S1_QP, K_S1_H32, K_S1_H2, K_S1_RES32, K_S1_RES32F,
-            K_S2_V2, K_S2_ONE, K_S2_GENERIC, K_T_ONE, K_T_GENERIC, K_UP0, K_UPQ, K_UPC, K_UPC_H, K_UPC_H2, K_HEAD_MFMA, K_HEAD_1X1 };
-
-struct Choice {
-    Kern k = K_NONE;
-    TileGeom g{};               // the pixel tiling the kernel walks
-    int bn = 0;                 // output columns per workgroup
-    int ksplit = 1;
-    bool fused_stats = false;   // per-tile partial statistics come out of the kernel's epilogue (else stats_direct / splitk_reduce_stats)
-    bool first_full = false;    // (K_FIRST*) complete one-image 256-pixel tiles: the persistent variant
-    bool flex = false;          // (K_UPC / K_UPC_H) the level is no multiple of 8 x 32: the FLEX instance on the extent-following tile c.g
-};
-
 inline bool fits32(size_t bytes) { return bytes < ((size_t)1 << 31); }      // an image addressed through a 32-bit buffer offset
 // the persistent kernels decode a tile number with udiv_magic (kernels.h): exact for tile number x tiles per image < 2^32
 inline bool magic_ok(const TileGeom& g) { return (unsigned long long)g.n_mtiles * (unsigned)(g.tiles_x * g.tiles_y) < 0x100000000ull; }
@@ -1020,6 +1026,16 @@ Choice choose(const ts2d_engine* e, size_t oi, int B, int H, int W) {
     }
     c.k = one ? K_S1_ONE : K_S1_GENERIC;
     return c;
+}
+
+// choose() for every op, cached per (B, H, W, precision, option generation)
+const std::vector<Choice>& planned(ts2d_engine* e, int B, int H, int W) {
+    if (e->plan.size() != e->ops.size() || e->planB != B || e->planH != H || e->planW != W || e->plan_prec != e->precision || e->plan_gen != e->opt_gen) {
+        e->plan.resize(e->ops.size());
+        for (size_t i = 0; i < e->ops.size(); ++i) e->plan[i] = choose(e, i, B, H, W);
+        e->planB = B; e->planH = H; e->planW = W; e->plan_prec = e->precision; e->plan_gen = e->opt_gen;
+    }
+    return e->plan;
 }
 
 size_t partial_floats_needed(const ts2d_engine* e, int B, int H, int W) {
@@ -1286,10 +1302,11 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
         TRY(prof_end(e, st));
     }
     const float* wts = e->d_weights;
+    const std::vector<Choice>& plan = planned(e, B, H, W);
     for (size_t oi = 0; oi < e->ops.size(); ++oi) {
         const Op& op = e->ops[oi];
         const Tensor& src = e->tensors[op.src];
-        const Choice c = choose(e, oi, B, H, W);
+        const Choice& c = plan[oi];
         const TileGeom& g = c.g;
         unsigned long long* const prof = (e->dbg == 256 && e->d_prof) ? e->d_prof + 512 * oi : nullptr;
         // per-tile partials -> scale / shift of the op's output (the launches of an op end with it)
@@ -1316,7 +1333,11 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             fa.lgTH = g.lgTH; fa.lgTW = g.lgTW; fa.lgNIMG = ilog2(g.NIMG); fa.tiles_x = g.tiles_x; fa.tiles_y = g.tiles_y;
             fa.n_mtiles = g.n_mtiles; fa.PH = g.PH; fa.PW = g.PW;
             const int kp = (op.cin + 1) / 2, nt = op.cout / 32, P = g.PH * g.PW * g.NIMG;
-            const size_t smem = std::max((size_t)P * (2 * kp + 1) * sizeof(float), (size_t)4 * op.cout * 4 * sizeof(float));
+            size_t smem = std::max((size_t)P * (2 * kp + 1) * sizeof(float), (size_t)4 * op.cout * 4 * sizeof(float));
+            if (f16 && c.first_full && nt == 1) {          // per-wave transpose regions of the 16-byte-store epilogue (kernels_first.h)
+                fa.tr_off = (int)align_up(smem, 16);
+                smem = fa.tr_off + 4 * kFirstTr;
+            }
             TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_first");
             // complete one-image 256-pixel tiles everywhere: persistent workgroups (4 per CU) with the next tile's patch in flight
             const bool first_full = c.first_full;
@@ -1723,6 +1744,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
     }
     if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0 flex)", name);
     e->ws_precision = -1;         // which ops compose (and with it the activation plan) depends on the options: re-plan at the next reserve / forward
+    ++e->opt_gen;
     return TS2D_OK;
 }
 
@@ -1908,13 +1930,13 @@ int ts2d_engine_check(ts2d_engine* e) {
         if (hipMalloc(reinterpret_cast<void**>(&d_copy), nb) == hipSuccess && hipMemcpy(d_copy, e->last_input, nb, hipMemcpyDeviceToDevice) == hipSuccess) {
             e->keep_activations = true;
             const bool was_fuse0 = e->use_fuse0;
-            e->use_fuse0 = false;             // (the first block as its own kernel: its output can be scanned and named)
+            e->use_fuse0 = false; ++e->opt_gen;      // (the first block as its own kernel: its output can be scanned and named)
             hipStream_t st = e->last_stream ? e->last_stream : e->stream;
             const bool prof = e->profiling; e->profiling = false;
             if (ensure_workspace(e, B, H, W) != TS2D_OK || run_forward(e, d_copy, B, H, W, nullptr, nullptr, st, false) != TS2D_OK ||
                 hipStreamSynchronize(st) != hipSuccess) { /* keep the generic message */ }
             e->profiling = prof;
-            e->use_fuse0 = was_fuse0;
+            e->use_fuse0 = was_fuse0; ++e->opt_gen;
             e->last_input = nullptr;
         }
     }
