@@ -92,7 +92,8 @@ int ts2d_engine_set_precision(ts2d_engine* e, int mode);
  *   level-0 composed kernel | "u0seg" (int) its tiles per workgroup segment, 0 = automatic | "q" persistent 16x32-tile stride-1 kernel |
  *   "one" one-image-tile kernels | "res" resident-weight 32 -> 32 kernel | "fuse0" first block recomputed inside the second |
  *   "s2v2" 512-thread stride-2 kernel | "h32", "h2", "h2_min" (int), "uh2": the 16-bit mode's variants | "flex" the composed decoder
- *   entry on tiles that follow the level's extent where it is no multiple of 8 x 32 pixels (0: transposed conv + conv there).
+ *   entry on tiles that follow the level's extent where it is no multiple of 8 x 32 pixels (0: transposed conv + conv there) |
+ *   "flex2" (int) the 512-thread stride-2 kernel on tiles that divide such a level (0: off, 1: 16-bit mode only, 2: every mode).
  * Unknown names and out-of-range values return TS2D_ERR_INVALID.  The reference has no counterpart (one code path through torch:
  * ts2d/core/inference/prediction_worker.py:209); the callers are this repo's tests and A/B scripts. */
 int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value);

@@ -132,7 +132,7 @@ struct Choice {
     int ksplit = 1;
     bool fused_stats = false;   // per-tile partial statistics come out of the kernel's epilogue (else stats_direct / splitk_reduce_stats)
     bool first_full = false;    // (K_FIRST*) complete one-image 256-pixel tiles: the persistent variant
-    bool flex = false;          // (K_UPC / K_UPC_H) the level is no multiple of 8 x 32: the FLEX instance on the extent-following tile c.g
+    bool flex = false;          // (K_UPC / K_UPC_H / K_S2_V2) the level is no multiple of 8 x 32: the FLEX instance on the tile c.g
 };
 
 
@@ -172,6 +172,7 @@ struct ts2d_engine {
     bool use_upc = true;          // "upc": decoder c0 blocks composed with their transposed conv (0: two kernels)
     bool use_res = true;          // "res": resident-weight kernel of the 32 -> 32 blocks
     bool use_fuse0 = true;        // "fuse0": first block recomputed inside the second (statistics-only pre-pass + conv3x3_res32 fused variant)
+    int use_flex2 = 2;            // "flex2": conv3x3s2_v2 on level-dividing tiles where the level is no multiple of 8 x 32 (0: off, 1: 16-bit mode only, 2: both)
     bool use_flex = true;         // "flex": the composed decoder entry on extent-following tiles at levels that are no multiple of 8 x 32 (0: two kernels there)
     int dbg = 0;                  // TS2D_DBG (the one environment switch left): timing ablations / in-kernel phase stamps of diagnostic runs
     unsigned long long* d_prof = nullptr;     // TS2D_DBG=256: in-kernel phase counters, 8 per op (diagnostic)
@@ -725,6 +726,26 @@ TileGeom tile_geom_upc(int B, int Ht, int Wt, bool& ok) {
     return g;
 }
 
+// Output tile of conv3x3s2_v2<.., FLEX> on a level that is no multiple of 8 x 32: TH | Ht, TW | Wt, TW % 4 == 0, TH * TW <= 256, a patch of
+// (2 TH + 1) x (2 TW + 2) <= 1122 slots; the largest such tile; ok = false below 3/4 of 256 pixels.
+TileGeom tile_geom_s2v2(int B, int Ht, int Wt, bool& ok) {
+    ok = false;
+    TileGeom g{};
+    int best = 0;
+    for (int tw = 4; tw <= std::min(Wt, 124); tw += 4) {
+        if (Wt % tw) continue;
+        for (int th = 1; th <= std::min(Ht, 256 / tw); ++th) {
+            if (Ht % th || (2 * th + 1) * (2 * tw + 2) > 1122) continue;
+            if (th * tw > best || (th * tw == best && tw > g.TW)) { best = th * tw; g.TH = th; g.TW = tw; }
+        }
+    }
+    if (best < 192) return g;
+    ok = true;
+    g.NIMG = 1;
+    tile_finish(g, B, Ht, Wt, 2, 2, 9);
+    return g;
+}
+
 // the 8 x 32 / 16 x 32 tilings of the kernels that walk complete tiles of a fixed shape
 TileGeom tile_fixed(int B, int Ht, int Wt, int th, int tw, int sy, int sx) {
     TileGeom g{};
@@ -985,6 +1006,12 @@ Choice choose(const ts2d_engine* e, size_t oi, int B, int H, int W) {
             c.k = K_S2_V2; c.bn = op.bn2; c.fused_stats = true;
             c.g = tile_fixed(B, Ht, Wt, 8, 32, 2, 2);
             return c;
+        }
+        if (op.s2v2_ok && e->use_s2v2 && e->use_one && e->use_flex2 && img32 && (f16 || e->use_flex2 > 1)) {
+            // ... on the tile that divides the level (FLEX instance)
+            bool ok = false;
+            const TileGeom gs = tile_geom_s2v2(B, Ht, Wt, ok);
+            if (ok && magic_ok(gs)) { c.k = K_S2_V2; c.bn = op.bn2; c.fused_stats = true; c.flex = true; c.g = gs; return c; }
         }
         c.g = tile_geom(B, Ht, Wt, 2, 2, 9);
         c.ksplit = choose_ksplit(op, c.g);
@@ -1549,14 +1576,16 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 const int grid2 = std::min(grid, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));
                 const size_t smem2 = (size_t)npp * 2 * kS2Plane + (resw ? (size_t)(op.cin / 16) : 1) * wchunk;
                 prof_kernel(e, op.bn2 == 128 ? "conv3x3s2_v2<128>" : "conv3x3s2_v2<64>");
-#define TS2D_S2V2_LAUNCH(BN_, ST_, NP_) do { static std::atomic<uint64_t> done_{0}, doner_{0}; \
-                    if (resw) { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, true>), doner_)); \
-                                hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, true>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } \
-                    else { HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, false>), done_)); \
-                           hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, false>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } } while (0)
+#define TS2D_S2V2_INST(BN_, ST_, NP_, RW_, FX_) do { static std::atomic<uint64_t> done_{0}; \
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, RW_, FX_>), done_)); \
+                    hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, RW_, FX_>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } while (0)
+#define TS2D_S2V2_LAUNCH(BN_, ST_, NP_) do { \
+                    if (resw) { if (c.flex) TS2D_S2V2_INST(BN_, ST_, NP_, true, true); else TS2D_S2V2_INST(BN_, ST_, NP_, true, false); } \
+                    else { if (c.flex) TS2D_S2V2_INST(BN_, ST_, NP_, false, true); else TS2D_S2V2_INST(BN_, ST_, NP_, false, false); } } while (0)
                 if (op.bn2 == 128) { if (f16) TS2D_S2V2_LAUNCH(128, _Float16, 1); else TS2D_S2V2_LAUNCH(128, float, 3); }
                 else { if (f16) TS2D_S2V2_LAUNCH(64, _Float16, 1); else TS2D_S2V2_LAUNCH(64, float, 3); }
 #undef TS2D_S2V2_LAUNCH
+#undef TS2D_S2V2_INST
                 le = hipGetLastError();
                 break;
             }
@@ -1735,14 +1764,14 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
     struct I { const char* n; int* p; int lo, hi; };
     const B bools[] = {{"h32", &e->use_h32}, {"one", &e->use_one}, {"s2v2", &e->use_s2v2}, {"q", &e->use_q}, {"h2", &e->use_h2},  {"uh2", &e->use_uh2},
                        {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}, {"flex", &e->use_flex}};
-    const I ints[] = {{"upq_min", &e->upq_min, 0, 1 << 20}, {"h2_min", &e->h2_min, 0, 1 << 20}, {"u0seg", &e->u0seg, 0, 1 << 20}};
+    const I ints[] = {{"upq_min", &e->upq_min, 0, 1 << 20}, {"h2_min", &e->h2_min, 0, 1 << 20}, {"u0seg", &e->u0seg, 0, 1 << 20}, {"flex2", &e->use_flex2, 0, 2}};
     bool found = false;
     for (const B& b : bools) if (!strcmp(name, b.n)) { *b.p = value != 0; found = true; }
     for (const I& i : ints) if (!strcmp(name, i.n)) {
         if (value < i.lo || value > i.hi) return fail(TS2D_ERR_INVALID, "option %s = %d out of range [%d, %d]", name, value, i.lo, i.hi);
         *i.p = value; found = true;
     }
-    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0 flex)", name);
+    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0 flex flex2)", name);
     e->ws_precision = -1;         // which ops compose (and with it the activation plan) depends on the options: re-plan at the next reserve / forward
     ++e->opt_gen;
     return TS2D_OK;

@@ -48,7 +48,12 @@ static_assert(kS2Plane % 128 == 64, "plane stride of conv3x3s2_v2");
 // LDS for the workgroup's life when it fits beside the patch (enc1.c0: 2 x 36 KB), so the per-chunk weight staging disappears.
 // Padding is decided per tile: a unit of patch row 0 / column 0 on a top / left border tile stores zeros (stride 2, pad 1 and even
 // extents: the patch never leaves the image at the bottom or the right).
-template <int BN, typename ST, int NP, bool RESW>
+// FLEX (round 5): output tile a.TH x a.TW instead of 8 x 32 - any shape with TH | Ht, TW | Wt, TW % 4 == 0, TH * TW <= 256 and a patch of
+// (2 TH + 1) rows x (2 TW + 2) slots <= 1122 (the engine picks it: 5 x 48 for a level of 80 x 48, 7 x 36 for 28 x 36 / 56 x 72, 16 x 16 for
+// the 16 x 16 level of the canonical net).  Tiles divide the level exactly, so - as with the fixed tile - a patch leaves the image at the top
+// and the left only.  Row m of the tile's GEMM is pixel (m / TW, m % TW): lane bases by division (once), tap offsets in registers, rows
+// past TH * TW read a dummy slot and are masked in the epilogue (which addresses per run of 4 pixels).
+template <int BN, typename ST, int NP, bool RESW, bool FLEX = false>
 __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) {
     constexpr int NPP = NP == 3 ? 2 : 1;                   // fp16 parts per value
     constexpr int NTW = BN / 64;                           // 32-column MFMA tiles per wave (a wave owns BN / 2 columns)
@@ -62,6 +67,8 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int TH = FLEX ? a.TH : 8, TW = FLEX ? a.TW : 32;
+    const int PW2 = FLEX ? 2 * TW + 2 : kS2PW, HO = FLEX ? TW + 1 : 33, PSL = FLEX ? (2 * TH + 1) * PW2 : kS2Slots;      // patch row pitch, odd-column offset, slots
 
     // ---- this workgroup's tiles: virtual block v = blockIdx.x + k * gridDim.x -> (xcd, column tile) fixed, pixel tile mtile0 + k * mstep
     const int xcd = blockIdx.x & 7, q80 = blockIdx.x >> 3;
@@ -92,12 +99,12 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
 #pragma unroll
     for (int it = 0; it < MAXU; ++it) {
         const int q = slot0 + USTEP * it;
-        const int py = q / kS2PW, rem = q - py * kS2PW;
-        const int half = rem >= 33 ? 1 : 0, px = 2 * (rem - 33 * half) + half;
-        const bool exists = q < kS2Slots && px <= 64;
+        const int py = q / PW2, rem = q - py * PW2;
+        const int half = rem >= HO ? 1 : 0, px = 2 * (rem - HO * half) + half;
+        const bool exists = q < PSL && px <= 2 * TW;
         rel[it] = exists ? (unsigned)(((py * a.Win + px) * a.C0) * (int)sizeof(ST) + 16 * sub) : 0x80000000u;
         if (exists) emask |= ((py == 0 ? 1u : 0u) | (px == 0 ? 2u : 0u)) << (2 * it);
-        if (q < kS2Slots && !exists) {                     // the unused 66th slot of a row: zero once (never staged, read by no fragment)
+        if (q < PSL && !exists) {                          // the unused last slot of a row: zero once (never staged, read by no fragment)
             if constexpr (F32) {
                 *reinterpret_cast<uint2*>(sA + lw0 + it * USTEP * 16) = uint2{0u, 0u};
                 if (NPP == 2) *reinterpret_cast<uint2*>(sA + lw0 + it * USTEP * 16 + 2 * kS2Plane) = uint2{0u, 0u};
@@ -153,7 +160,8 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
                                                  (int)(img_px * a.C0 * sizeof(ST)), 0x00020000);
         // patch origin (2 ty0 - 1, 2 tx0 - 1) may lie one row / column outside the image: unsigned wrap-around is fine, the affected
         // units are padding (zeroed at conversion)
-        q.org = (unsigned)((((16 * tyi - 1) * a.Win + 64 * txi - 1) * a.C0) * (int)sizeof(ST));
+        q.org = FLEX ? (unsigned)((((2 * TH * tyi - 1) * a.Win + 2 * TW * txi - 1) * a.C0) * (int)sizeof(ST))
+                     : (unsigned)((((16 * tyi - 1) * a.Win + 64 * txi - 1) * a.C0) * (int)sizeof(ST));
         q.soff = t.c * 16 * (int)sizeof(ST);
         return q;
     };
@@ -180,6 +188,15 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
 
     // ---- lane constants of the MFMA phase: output pixel (2 wm + mt, r) reads patch row 2 (2 wm + mt) + dy, slot (dx & 1) 33 + r + (dx >> 1)
     const int abase = h * kS2Plane + ((4 * wm) * kS2PW + r) * 16;                  // + mt * 2 * 66 * 16 + part * 2 * Plane + tap offset
+    int fxb[2] = {0, 0};                                                           // FLEX: per M tile (row m = 64 wm + 32 mt + r -> pixel (m / TW, m % TW): patch row 2 ty, slot tx)
+    if constexpr (FLEX) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = 64 * wm + 32 * mt + r;
+            const int ty = fdiv(m, a.inv_tw), tx = m - ty * TW;
+            fxb[mt] = h * kS2Plane + (m < TH * TW ? (2 * ty * PW2 + tx) * 16 : 0);
+        }
+    }
     const int bbase = NPP * 2 * kS2Plane + h * BN * 16 + (wn * (BN / 2) + r) * 16;  // + chunk * WB (RESW) + tap * WTAP + part * 2 * BN * 16 + nt * 512
     const _Float16 slope_h = (_Float16)a.slope;
     const unsigned slope2 = (unsigned)__builtin_bit_cast(unsigned short, slope_h) * 0x10001u;
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     auto item = [&](Stage& S) {                            // one (tile, chunk) item: conversion from S, next request into S, MFMAs, epilogue
         int nimg0, tyi, txi, tin;
         tile_origin(cur.k, nimg0, tyi, txi, tin);
-        const int ty0 = tyi * 8, tx0 = txi * 32;
+        const int ty0 = tyi * TH, tx0 = txi * TW;
         TS2D_STAMP_AT(a.prof, 3)
         lds_barrier();                                     // the previous item's MFMA reads of LDS (and its statistics exchange) are done
         TS2D_STAMP_AT(a.prof, 1)                           // (LDS-only barriers: a __syncthreads() here would wait for the previous tile's output stores)
@@ -267,11 +284,12 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         // loop waited for every tap's reads before its MFMAs)
         auto load_frags = [&](half8 (&fa)[2][NPP], half8 (&fb)[NTW][NPP], int tap) {
             const int dy = tap / 3, dx = tap - 3 * dy;
-            const int toff = (dy * kS2PW + (dx & 1) * 33 + (dx >> 1)) * 16;
+            const int toff = (dy * PW2 + (dx & 1) * HO + (dx >> 1)) * 16;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int p = 0; p < NPP; ++p) fa[mt][p] = *reinterpret_cast<const half8*>(smem8 + abase + mt * 2 * kS2PW * 16 + p * 2 * kS2Plane + toff);
+                for (int p = 0; p < NPP; ++p)
+                    fa[mt][p] = *reinterpret_cast<const half8*>(smem8 + (FLEX ? fxb[mt] : abase + mt * 2 * kS2PW * 16) + p * 2 * kS2Plane + toff);
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
@@ -324,9 +342,46 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
             const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
             const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * sizeof(ST)), 0x00020000);
             float st_s[NTW], st_q[NTW], st_k[NTW];
+            float nvalid = 64.f;                                   // pixels of this wave inside the tile
             float bvs[NTW];       // every bias value before the first store: a load issued between stores waits (in-order vmcnt) for the stores ahead of it
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) bvs[nt] = a.bias[n0col + wn * (BN / 2) + nt * 32 + r];
+            if constexpr (FLEX) {
+                // a lane's 16 rows of an M tile = 4 runs of 4 consecutive pixels (TW % 4 == 0: a run stays inside one tile row): one division and
+                // one address per run; runs past TH * TW are dropped (out-of-range offset) and kept out of the statistics
+                const int thw = TH * TW;
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    st_k[nt] = stat_pivot(round_act<ST>(__builtin_fmaf(acc_t[0][nt][0], oscale, bvs[nt])));
+                    st_s[nt] = 0.f; st_q[nt] = 0.f;
+                }
+                int cnt = 0;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int m0 = 64 * wm + 32 * mt + 4 * h + 8 * j;
+                        asm volatile("" : "+v"(m0));               // (not hoisted out of the tile loop into 16 live registers)
+                        const int ty = fdiv(m0, a.inv_tw), tx = m0 - ty * TW;
+                        const bool ok = m0 < thw;
+                        const unsigned vrun = ok ? (unsigned)((((ty0 + ty) * a.Wt + tx0 + tx) * a.Cout + n0col + wn * (BN / 2) + r) * (int)sizeof(ST)) : 0x80000000u;
+                        cnt += ok ? 4 : 0;
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4)
+#pragma unroll
+                            for (int nt = 0; nt < NTW; ++nt) {
+                                const int i2 = 4 * j + e4;
+                                float v = __builtin_fmaf(acc_t[mt][nt][i2], oscale, bvs[nt]);
+                                buffer_store_act<ST>(v, rsd, vrun, (unsigned)((e4 * a.Cout + nt * 32) * (int)sizeof(ST)));
+                                const float d = ok ? round_act<ST>(v) - st_k[nt] : 0.f;
+                                st_s[nt] += d; st_q[nt] = __builtin_fmaf(d, d, st_q[nt]);
+                                acc_t[mt][nt][i2] = 0.f;
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                cnt += __shfl_xor(cnt, 32);
+                nvalid = (float)cnt;
+            } else {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int co = n0col + wn * (BN / 2) + nt * 32 + r;
@@ -349,6 +404,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
                 }
                 st_s[nt] = s; st_q[nt] = q; st_k[nt] = kv;
             }
+            }
             TS2D_STAMP_AT(a.prof, 4)
             lds_barrier();                                         // every wave is done with the LDS images (the output stores stay in flight)
             float* red = reinterpret_cast<float*>(smem8);          // [wm 4][column BN] x (S, Q, K, n)
@@ -356,7 +412,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
             for (int nt = 0; nt < NTW; ++nt) {
                 float s = st_s[nt], q = st_q[nt];
                 s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-                if (h == 0) stat_wave_put(red, wm * BN + wn * (BN / 2) + nt * 32 + r, s, q, st_k[nt], 64.f);
+                if (h == 0) stat_wave_put(red, wm * BN + wn * (BN / 2) + nt * 32 + r, s, q, st_k[nt], nvalid);
             }
             lds_barrier();
             if (tid < BN) stat_tile_store(red, 4, BN, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + n0col + tid) * 4);
