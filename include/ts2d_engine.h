@@ -36,7 +36,8 @@ typedef enum {
  * `nnUNetPredictor.initialize_from_trained_model_folder` (reference call site ts2d/core/inference/nnu.py:165) reads
  * from plans.json.  Supported subset: Conv2d 3x3, stride (1, 1) in the first stage and 1 or 2 PER AXIS afterwards (nnU-Net's
  * planner pools each axis separately: (2, 2) until one axis is exhausted, then (2, 1) / (1, 2)), InstanceNorm2d(affine), LeakyReLU,
- * ConvTranspose2d upsampling with kernel = stride = the stride of the stage below, 1x1 head.  features[] must be multiples of 32.
+ * ConvTranspose2d upsampling with kernel = stride = the stride of the stage below, 1x1 head.  features[]: any positive width, features[0] <= 64; a width that
+ * is not a multiple of 32 runs rounded up to one with zero weights in the added channels (exact; the weight blob keeps the caller's layout).
  * (2, 2) stages run the dedicated kernels; any other stride runs a generic implicit-GEMM kernel (correct, not tuned). */
 typedef struct {
     int32_t input_channels;                 /* C: len(dataset_json['channel_names']) (prediction_worker.py:78) */

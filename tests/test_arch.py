@@ -58,8 +58,11 @@ def test_per_axis_strides():
 def test_validate_rejects_unsupported():
     with pytest.raises(NotImplementedError):
         UNetArch(kernel_sizes=((5, 5),) * 8).validate()
+    UNetArch(features_per_stage=(30, 64, 100, 256, 512, 512, 512, 512)).validate()        # any width (the engine rounds a stage up, zero weights)
     with pytest.raises(NotImplementedError):
-        UNetArch(features_per_stage=(30, 64, 128, 256, 512, 512, 512, 512)).validate()
+        UNetArch(features_per_stage=(96, 128, 128, 256, 512, 512, 512, 512)).validate()    # the head kernel reads at most 64 channels
+    with pytest.raises(ValueError):
+        UNetArch(features_per_stage=(32, 0, 128, 256, 512, 512, 512, 512)).validate()
     with pytest.raises(ValueError):
         UNetArch(n_conv_per_stage=(2,) * 7).validate()
 

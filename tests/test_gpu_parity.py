@@ -319,6 +319,42 @@ def test_per_axis_strides_in_every_precision_mode(name):
             assert got.shape == want.shape and _f16_layer_ok(n, got, want), (n, float(np.abs(got - want).max()), float(np.sqrt(np.mean((got - want) ** 2))))
 
 
+@pytest.mark.parametrize('feats,strides', [((24, 40, 72), None), ((16, 48, 80, 100), [(1, 1), (2, 2), (2, 2), (2, 1)]), ((40, 40), None)])
+def test_stage_widths_that_are_not_multiples_of_32(feats, strides):
+    """A plans.json may name any features_per_stage (the reference builds whatever arch_kwargs say: ts2d/core/inference/nnu.py:164-165).
+    The engine runs such a stage rounded up to a multiple of 32 with zero weights / bias / gamma / beta in the added channels
+    (csrc/engine.hip pad_arch / expand_blob) - exact, so the tolerance is the usual one; the weight blob and every tensor read back
+    keep the caller's widths."""
+    from oracle import torch_oracle as O
+    arch = cases.unet(len(feats), feats, 5, cin=2, nconv=2, strides=strides)
+    sd, blob = blob_for(arch, 77)
+    dy, dx = arch.divisors
+    B, H, W = 3, 8 * dy, 32 * dx
+    x = cases.make_input(arch, B, H, W, 77)
+    ref, inter = O.unet_forward(arch, sd, x, return_intermediates=True)
+    ref16 = O.unet_forward(arch, sd, x, emulate='f16').numpy()
+    with Engine(arch, blob) as e:
+        for mode in ('exact', 'split'):
+            e.set_precision(mode)
+            lg, mk = e.forward(x, logits=True, mask=True)
+            assert np.abs(lg - ref.numpy()).max() <= TOL, mode
+            assert np.array_equal(unpack_mask(mk, W), _oracle_mask(lg))
+        e.set_option('upc', 0); e.set_option('fuse0', 0)          # (every tensor materialised)
+        e.forward(x, logits=True)
+        for n, want in inter.items():
+            got = e.debug_tensor(n)
+            assert got.shape == tuple(want.shape), (n, got.shape)
+            assert np.abs(got - want.numpy()).max() <= TOL, n
+        e.set_option('upc', 1); e.set_option('fuse0', 1)
+        e.set_precision('f16')
+        lg, _ = e.forward(x, logits=True)
+        d = lg - ref16
+        assert np.abs(d).max() <= F16E_MAX and np.sqrt((d ** 2).mean()) <= F16E_RMS
+        # a blob of the rounded-up architecture's size is refused: the caller's layout is the contract
+        with pytest.raises(RuntimeError, match='weight blob has'):
+            e.load_weights(np.zeros(blob.size + 1, np.float32))
+
+
 def _level_kernels(kern, lo, hi):
     return {n: k for n, k in kern.items() if not n.endswith('.stats') and n != 'head' and lo <= int(n[3:n.index('.')]) <= hi}
 

@@ -109,8 +109,12 @@ class UNetArch:
             raise NotImplementedError("conv_bias=False / affine=False are not supported")
         if self.input_channels < 1 or self.num_classes < 1:
             raise ValueError("input_channels and num_classes must be positive")
-        if any(f % 32 for f in self.features_per_stage):
-            raise NotImplementedError("features_per_stage must be multiples of 32 for the MFMA tiling")
+        # (any width: the engine rounds a stage up to a multiple of 32 with zero weights in the added channels - exact, csrc/engine.hip pad_arch;
+        #  the head kernel reads at most 64 channels)
+        if any(f < 1 for f in self.features_per_stage):
+            raise ValueError("features_per_stage must be positive")
+        if self.features_per_stage[0] > 64:
+            raise NotImplementedError(f"features_per_stage[0] = {self.features_per_stage[0]}: the 1x1 head kernel supports at most 64 channels")
         if any(c < 1 for c in list(self.n_conv_per_stage) + list(self.n_conv_per_stage_decoder)):
             raise ValueError("n_conv_per_stage* must be >= 1")
 

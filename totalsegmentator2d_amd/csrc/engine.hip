@@ -61,6 +61,7 @@ enum OpType { OP_CONV = 0, OP_CONVT = 1, OP_HEAD = 2 };
 struct Tensor {            // an activation tensor of the program (NHWC fp32)
     std::string name;
     int C = 0, level = 0;
+    int Cu = 0;            // channels of the CALLER's architecture (C is the width the kernels run: rounded up to 32 - pad_arch)
     int ly = 0, lx = 0;    // log2 of the cumulative stride along H / W: extent (H >> ly, W >> lx) (per-axis strides, ABI 7)
     bool normed = false;   // raw conv output that carries InstanceNorm scale/shift
     float* data = nullptr; float* scale = nullptr; float* shift = nullptr;
@@ -149,6 +150,9 @@ struct ts2d_engine {
     std::vector<Tensor> tensors;
     std::vector<Op> ops;
     size_t blob_floats = 0;
+    ts2d_arch_desc user_arch{};        // the descriptor the caller gave; `arch` is what the kernels run (pad_arch)
+    bool padded = false;
+    size_t user_blob_floats = 0;       // floats of the caller's blob (== blob_floats unless padded)
     float* d_weights = nullptr; size_t weight_floats = 0;
     bool weights_ready = false;
     int precision = TS2D_PRECISION_F32_SPLIT_F16X3;
@@ -211,8 +215,78 @@ int tensor_index(ts2d_engine* e, const std::string& name) {
 
 int add_tensor(ts2d_engine* e, const std::string& name, int C, int level, bool normed) {
     Tensor t; t.name = name; t.C = C; t.level = level; t.normed = normed; t.ly = e->lvl_y[level]; t.lx = e->lvl_x[level];
+    t.Cu = (name == "input") ? C : e->user_arch.features[level];
     e->tensors.push_back(t);
     return (int)e->tensors.size() - 1;
+}
+
+// Feature counts the MFMA tilings do not divide ("a descriptor-driven engine needs a correct generic path for what it
+// cannot make fast"): every stage's width is rounded up to a multiple of 32 (stage 0: to 32 or 64, what the head kernel reads) and the network
+// runs at that width with ZERO weights, bias, gamma and beta in the added channels.  Exact, not approximate: an added channel's conv output is
+// 0 in every pixel, its InstanceNorm scale gamma * rsqrt(0 + eps) = 0 and shift 0, so it enters the next layer as LeakyReLU(0) = 0 under zero
+// weights; the caller's channels see the same sums with zeros added.  The caller's blob keeps the caller's layout (expand_blob below).
+ts2d_arch_desc pad_arch(const ts2d_arch_desc& a, bool& padded) {
+    ts2d_arch_desc p = a;
+    padded = false;
+    for (int s = 0; s < a.n_stages && s < TS2D_MAX_STAGES; ++s) {
+        if (a.features[s] < 1) continue;                       // (build_program reports it)
+        p.features[s] = (a.features[s] + 31) / 32 * 32;
+        padded |= p.features[s] != a.features[s];
+    }
+    return p;
+}
+
+// The parameter tensors of a descriptor in state-dict order, as (rows, columns of the first / second source, inner) blocks; vectors have inner 0.
+struct ParamSeg { int rows, ca, cb, inner; };
+std::vector<ParamSeg> param_segs(const ts2d_arch_desc& a) {
+    std::vector<ParamSeg> v;
+    auto stride_of = [&](int s, int ax) { const int y = a.strides[s][0], x = a.strides[s][1]; return (y == 0 && x == 0) ? (s ? 2 : 1) : (ax ? x : y); };
+    int cin = a.input_channels;
+    for (int s = 0; s < a.n_stages; ++s)
+        for (int i = 0; i < a.n_conv_enc[s]; ++i) {
+            const int f = a.features[s];
+            v.push_back({f, cin, 0, 9}); v.push_back({f, 0, 0, 0}); v.push_back({f, 0, 0, 0}); v.push_back({f, 0, 0, 0});
+            cin = f;
+        }
+    for (int j = 0; j < a.n_stages - 1; ++j) {
+        const int lvl = a.n_stages - 2 - j, f = a.features[lvl];
+        v.push_back({cin, f, 0, stride_of(lvl + 1, 0) * stride_of(lvl + 1, 1)}); v.push_back({f, 0, 0, 0});      // ConvTranspose2d weight [Cin][Cout][sy][sx], bias
+        for (int i = 0; i < a.n_conv_dec[j]; ++i) {
+            v.push_back({f, f, i == 0 ? f : 0, 9}); v.push_back({f, 0, 0, 0}); v.push_back({f, 0, 0, 0}); v.push_back({f, 0, 0, 0});
+        }
+        cin = f;
+    }
+    v.push_back({a.num_classes, cin, 0, 1}); v.push_back({a.num_classes, 0, 0, 0});
+    return v;
+}
+
+size_t segs_floats(const std::vector<ParamSeg>& v) {
+    size_t n = 0;
+    for (const ParamSeg& g : v) n += g.inner ? (size_t)g.rows * (g.ca + g.cb) * g.inner : (size_t)g.rows;
+    return n;
+}
+
+// caller-layout blob -> the blob of the padded architecture (zeros in every added row / column; the second source of a decoder block's
+// first conv - the skip half of cat((up, skip), 1) - starts at the PADDED width of the first)
+void expand_blob(const ts2d_arch_desc& ua, const ts2d_arch_desc& pa, const float* ub, std::vector<float>& pb) {
+    const std::vector<ParamSeg> us = param_segs(ua), ps = param_segs(pa);
+    pb.assign(segs_floats(ps), 0.f);
+    size_t uo = 0, po = 0;
+    for (size_t k = 0; k < us.size(); ++k) {
+        const ParamSeg &u = us[k], &q = ps[k];
+        if (!u.inner) {
+            memcpy(pb.data() + po, ub + uo, (size_t)u.rows * sizeof(float));
+            uo += u.rows; po += q.rows;
+            continue;
+        }
+        const int ucols = u.ca + u.cb, qcols = q.ca + q.cb;
+        for (int r = 0; r < u.rows; ++r)
+            for (int c = 0; c < ucols; ++c) {
+                const int cq = c < u.ca ? c : q.ca + (c - u.ca);
+                memcpy(pb.data() + po + ((size_t)r * qcols + cq) * q.inner, ub + uo + ((size_t)r * ucols + c) * u.inner, (size_t)u.inner * sizeof(float));
+            }
+        uo += (size_t)u.rows * ucols * u.inner; po += (size_t)q.rows * qcols * q.inner;
+    }
 }
 
 // Mirror of UNetArch.program() (totalsegmentator2d_amd/arch.py): PlainConvUNet forward order.
@@ -222,11 +296,11 @@ int build_program(ts2d_engine* e) {
     if (a.input_channels < 1 || a.num_classes < 1) return fail(TS2D_ERR_INVALID, "input_channels / num_classes must be positive");
     if (a.num_classes > 256) return fail(TS2D_ERR_INVALID, "num_classes %d > 256 is not supported", a.num_classes);
     for (int s = 0; s < a.n_stages; ++s) {
-        if (a.features[s] < 32 || a.features[s] % 32) return fail(TS2D_ERR_INVALID, "features[%d] = %d must be a positive multiple of 32", s, a.features[s]);
+        if (e->user_arch.features[s] < 1) return fail(TS2D_ERR_INVALID, "features[%d] = %d must be positive", s, e->user_arch.features[s]);
         if (a.n_conv_enc[s] < 1) return fail(TS2D_ERR_INVALID, "n_conv_enc[%d] must be >= 1", s);
         if (s < a.n_stages - 1 && a.n_conv_dec[s] < 1) return fail(TS2D_ERR_INVALID, "n_conv_dec[%d] must be >= 1", s);
     }
-    if (a.features[0] != 32 && a.features[0] != 64) return fail(TS2D_ERR_INVALID, "features[0] = %d: the head kernel supports 32 or 64", a.features[0]);
+    if (a.features[0] != 32 && a.features[0] != 64) return fail(TS2D_ERR_INVALID, "features[0] = %d: the head kernel supports at most 64 channels", e->user_arch.features[0]);
     // per-axis strides (ABI 7).  An all-zero entry = (2, 2): descriptors written for ABI <= 6 carry no strides.
     int st[TS2D_MAX_STAGES][2];
     for (int s = 0; s < a.n_stages; ++s) {
@@ -287,6 +361,7 @@ int build_program(ts2d_engine* e) {
         e->ops.push_back(hd);
     }
     e->blob_floats = bo;
+    e->user_blob_floats = e->padded ? segs_floats(param_segs(e->user_arch)) : bo;
     // device weight arena layout
     size_t wo = 0;
     for (Op& op : e->ops) {
@@ -626,10 +701,13 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
 
 int upload_weights(ts2d_engine* e, const float* blob, size_t n_floats) {
     // (pack_weights also records the per-layer split scale in the op table)
-    if (n_floats != e->blob_floats)
-        return fail(TS2D_ERR_INVALID, "weight blob has %zu floats, architecture needs %zu", n_floats, e->blob_floats);
-    std::vector<float> staging;
-    try { staging.resize(e->weight_floats); } catch (...) { return fail(TS2D_ERR_NOMEM, "host staging allocation failed"); }
+    if (n_floats != e->user_blob_floats)
+        return fail(TS2D_ERR_INVALID, "weight blob has %zu floats, architecture needs %zu", n_floats, e->user_blob_floats);
+    std::vector<float> staging, wide;
+    try {
+        staging.resize(e->weight_floats);
+        if (e->padded) { expand_blob(e->user_arch, e->arch, blob, wide); blob = wide.data(); }
+    } catch (...) { return fail(TS2D_ERR_NOMEM, "host staging allocation failed"); }
     pack_weights(e, blob, staging.data());
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpy(e->d_weights, staging.data(), e->weight_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -1707,7 +1785,8 @@ int ts2d_engine_create(const ts2d_arch_desc* arch, const float* weights, size_t 
     if (device < 0 || device >= ndev) return fail(TS2D_ERR_INVALID, "device %d out of range (%d HIP devices visible)", device, ndev);
     ts2d_engine* e = new (std::nothrow) ts2d_engine();
     if (!e) return fail(TS2D_ERR_NOMEM, "host allocation failed");
-    e->arch = *arch; e->device = device;
+    e->user_arch = *arch; e->device = device;
+    if (arch->n_stages >= 2 && arch->n_stages <= TS2D_MAX_STAGES) e->arch = pad_arch(*arch, e->padded); else e->arch = *arch;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
@@ -2153,10 +2232,10 @@ int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_
         if (e->fused_away[oi] && e->ops[oi].dst == ti)
             return fail(TS2D_ERR_INVALID, "tensor '%s' was not materialised by the last run: the transposed conv is composed into the next block "
                         "(ts2d_engine_set_option(e, \"upc\", 0) runs it as its own kernel)", name);
-    const int B = e->lastB, h = e->lastH >> t.ly, w = e->lastW >> t.lx, C = t.C;
-    dims[0] = B; dims[1] = C; dims[2] = h; dims[3] = w;
+    const int B = e->lastB, h = e->lastH >> t.ly, w = e->lastW >> t.lx, C = t.C, Cu = t.Cu;      // (the caller's channels; C - Cu added ones hold zeros)
+    dims[0] = B; dims[1] = Cu; dims[2] = h; dims[3] = w;
     const size_t n = (size_t)B * C * h * w;
-    if (capacity < n) return fail(TS2D_ERR_INVALID, "tensor '%s' needs %zu floats, capacity is %zu", name, n, capacity);
+    if (capacity < (size_t)B * Cu * h * w) return fail(TS2D_ERR_INVALID, "tensor '%s' needs %zu floats, capacity is %zu", name, (size_t)B * Cu * h * w, capacity);
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->last_stream ? e->last_stream : e->stream));
     std::vector<float> raw(n), sc, sh;
@@ -2174,10 +2253,10 @@ int ts2d_engine_debug_tensor(ts2d_engine* e, const char* name, float* out, size_
     }
     for (int b = 0; b < B; ++b)
         for (int p = 0; p < h * w; ++p)
-            for (int c = 0; c < C; ++c) {
+            for (int c = 0; c < Cu; ++c) {
                 float v = raw[((size_t)b * h * w + p) * C + c];
                 if (t.normed) { v = v * sc[(size_t)b * C + c] + sh[(size_t)b * C + c]; v = v > 0.f ? v : v * e->arch.leaky_slope; }
-                out[((size_t)b * C + c) * h * w + p] = v;
+                out[((size_t)b * Cu + c) * h * w + p] = v;
             }
     return TS2D_OK;
 }
