@@ -84,6 +84,8 @@ for t in range(n):
     feats = [32 * int(rng.choice([1, 1, 2])) for _ in range(ns)]
     for i in range(1, ns): feats[i] = max(feats[i], feats[i - 1]) * int(rng.choice([1, 2])) if feats[i - 1] < 256 else feats[i - 1]
     feats = [min(f, 256) for f in feats]
+    if rng.random() < 0.25:                                   # widths the MFMA tilings do not divide: the engine rounds them up with zero weights (exact)
+        feats = [max(8, f - int(rng.integers(0, 32))) for f in feats]
     K = int(rng.integers(1, 27)); cin = int(rng.integers(1, 4))
     mult = 2 ** (ns - 1)
     H = mult * int(rng.integers(1, max(2, 160 // mult) + 1)); W = mult * int(rng.integers(1, max(2, 160 // mult) + 1))
