@@ -152,3 +152,38 @@ def test_case_enumeration(tmp_path):
         _enumerate_cases(str(tmp_path / 'missing.nrrd'))
     with pytest.raises(ValueError, match='does not have an extension'):
         _enumerate_cases(str(tmp_path / 'noext'))
+
+
+def test_combined_segmentation_equals_the_composed_label_masks(tmp_path):
+    """``combine_segmentations`` (reference ts2d/core/util/image.py:490-510: per label of every sub-model the ``> 0`` mask, composed
+    into one vector image) writes its masks plane by plane and returns the interleaved VIEW; the values, the label order, the
+    metadata and what ``nrrd.write`` serialises must be those of the composed image - also for a label-map member and for a
+    member whose labels are listed out of channel order."""
+    from totalsegmentator2d_amd.export import segmentation_to_image
+    rng = np.random.default_rng(3)
+    ref = nrrd.Image(np.zeros((20, 12)), (1.5, 2.0), (3.0, 4.0), (1.0, 0.0, 0.0, 1.0), 1, {}, None)
+    a = segmentation_to_image((rng.random((3, 1, 20, 12)) > 0.5).astype(np.uint8) * 7, ref, True, {1: 'a1', 2: 'a2', 3: 'a3'}, None)
+    b = segmentation_to_image((rng.random((4, 1, 20, 12)) > 0.5).astype(np.uint8), ref, True, {1: 'b1', 2: 'b2', 3: 'b3', 4: 'b4'}, None)
+    assert not a.array.flags['C_CONTIGUOUS'] and a.array.shape == (20, 12, 3)
+    # labels of b out of channel order: Segment0 -> layer 2, Segment1 -> layer 0, ...
+    for i, layer in enumerate((2, 0, 3, 1)):
+        b.meta[f'Segment{i}_Layer'] = str(layer)
+    c = nrrd.Image(rng.integers(0, 3, (20, 12)).astype(np.uint8), ref.spacing, ref.origin, ref.direction, 1, {}, None)
+    image.set_annotation_meta(c, {1: 'c1', 2: 'c2'}, None)
+    got = image.combine_segmentations([a, b, c])
+    want, names = [], []
+    for seg in (a, b, c):
+        for name, info in image.get_annotation_labels(seg).items():
+            want.append(image.get_label_mask(seg, info['value']).array)
+            names.append(name)
+    want = np.stack(want, axis=-1)
+    assert got.components == 9 and got.array.shape == want.shape and got.array.dtype == np.uint8
+    assert np.array_equal(got.array, want)
+    assert list(image.get_annotation_labels(got)) == names
+    path = str(tmp_path / 'combined.nrrd')
+    nrrd.write(got, path, True)
+    back = nrrd.read(path)
+    assert back.components == 9 and np.array_equal(back.array, want) and back.spacing == got.spacing
+    one = image.combine_segmentations([nrrd.Image(c.array, c.spacing, c.origin, c.direction, 1,
+                                                  {k: v for k, v in c.meta.items() if not k.startswith('Segment1_')}, None)])
+    assert one.components == 1 and np.array_equal(one.array, (c.array == 1).astype(np.uint8))
