@@ -4,7 +4,7 @@ the reference's sample_s0616.nrrd (2 tiles x 4 mirror passes per sub-model): the
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from totalsegmentator2d_amd import weights
+
 from totalsegmentator2d_amd.arch import UNetArch
 from totalsegmentator2d_amd.model import HIPModel
 from totalsegmentator2d_amd.tool import TS2D

@@ -11,7 +11,7 @@ weight blob uses, and does the FLOP/byte accounting BASELINE.md quotes.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field, asdict
+from dataclasses import dataclass, asdict
 from typing import Dict, List, Sequence, Tuple
 
 OP_CONV3X3 = 0    # Conv2d 3x3 pad 1 (+bias) -> InstanceNorm2d(affine) -> LeakyReLU   (K1/K2/K3/K6)

@@ -112,7 +112,6 @@ def project_coronal_gpu(img: Image, device: int = 0, zscore: bool = False):
     ZScoreNormalization, float64 statistics - and returns them under ``'zscore'``: ``{'norm': [2, nz, nx] float32 in
     (max, mean) order, 'stats': (mean, std) x 2, 'box': non-zero bounding box}``; ``DefaultPreprocessor.run_case_npy`` uses it
     in place of its host pass when nnU-Net's crop-to-nonzero is the identity (``preprocess.py``)."""
-    import ctypes
     from . import _lib
     if img.dimension != 3 or img.components != 1 or img.array.dtype.name not in _GPU_DTYPES:
         raise RuntimeError(f"GPU projection needs a scalar 3-D volume of type {sorted(_GPU_DTYPES)}, found {img.array.dtype}")

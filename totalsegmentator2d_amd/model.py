@@ -10,7 +10,7 @@ import json
 import os
 import re
 import time
-from typing import Dict, List, Optional, Sequence, Union
+from typing import Dict, List, Optional, Union
 
 import numpy as np
 

@@ -21,7 +21,7 @@ import json
 import os
 import re
 from types import SimpleNamespace
-from typing import Callable, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 

@@ -9,7 +9,7 @@ upstream names are kept: ``compute_steps_for_sliding_window``, ``compute_gaussia
 from __future__ import annotations
 
 import itertools
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
