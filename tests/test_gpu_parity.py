@@ -355,6 +355,30 @@ def test_stage_widths_that_are_not_multiples_of_32(feats, strides):
             e.load_weights(np.zeros(blob.size + 1, np.float32))
 
 
+@pytest.mark.parametrize('H,W,cin', [(112, 16, 1), (32, 16, 2), (16, 64, 2), (8, 128, 1)])
+def test_f16_first_block_on_every_complete_tile_shape(H, W, cin):
+    """The 16-bit first block stores an M tile (32 consecutive GEMM rows) as 2 KB through a per-wave LDS transpose; on 16-wide tiles
+    (W = 16: the 256-pixel tile is 16 x 16) an M tile is TWO image rows, on 64- / 128-wide tiles a part of one.  Found by
+    scripts/gpu_fuzz_parity.py (seed 601, case 5: 112 x 16 - the store addressed the M tile as one row of a 32-wide tile and the
+    layer came back with inf): the layer is compared with the 16-bit oracle here on every tile shape the planner can choose."""
+    from oracle import torch_oracle as O
+    arch = cases.unet(3, (32, 64, 64), 4, cin=cin, nconv=1)
+    sd, blob = blob_for(arch, 31)
+    x = cases.make_input(arch, 2, H, W, 31)
+    ref16 = O.unet_forward(arch, sd, x, emulate='f16')
+    with Engine(arch, blob) as e:
+        e.set_precision('f16')
+        e.set_profiling(True)
+        lg, _ = e.forward(x, logits=True)
+        assert e.op_kernels()['enc0.c0'] == 'conv3x3_first'
+        got = e.debug_tensor('enc0.c0')
+        want = O.layer_forward(arch, sd, 'enc0.c0', x, emulate='f16', storage_view=True).numpy()
+        assert got.shape == want.shape and np.isfinite(got).all()
+        assert _f16_layer_ok('enc0.c0', got, want), (float(np.abs(got - want).max()), float(np.sqrt(np.mean((got - want) ** 2))))
+        d = lg - ref16.numpy()
+        assert np.abs(d).max() <= F16E_MAX and np.sqrt((d ** 2).mean()) <= F16E_RMS
+
+
 def _level_kernels(kern, lo, hi):
     return {n: k for n, k in kern.items() if not n.endswith('.stats') and n != 'head' and lo <= int(n[3:n.index('.')]) <= hi}
 

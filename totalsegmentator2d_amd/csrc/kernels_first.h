@@ -172,13 +172,14 @@ __global__ TS2D_PACKED_F32 __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 
                 }
                 nn += 16.f;
                 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-                const int oy = ty0 + 2 * w + mt;                                        // (TW = 32: the M tile is tile row 2 w + mt)
-                const unsigned rowoff = (unsigned)(((oy * a.W + tx0) * 32) * 2);
+                const int m0 = 64 * w + 32 * mt;                                        // first GEMM row of the M tile: tile pixel (m >> lgTW, m & (TW - 1))
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int piece = k * 64 + lane;                                    // 16-byte piece of the 2 KB: pixel piece / 4, part piece % 4
+                    const int m = m0 + (piece >> 2);                                    // (TW = 32: one tile row = 2 KB of contiguous output; TW = 16: two rows)
+                    const unsigned off = (unsigned)((((ty0 + (m >> a.lgTW)) * a.W + tx0 + (m & (TW - 1))) * 32) * 2 + (piece & 3) * 16);
                     const u32x4s q = *reinterpret_cast<const u32x4s*>(tw + (piece >> 2) * kFirstTrPitch + (piece & 3) * 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(q, rsd, rowoff + (unsigned)piece * 16u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(q, rsd, off, 0, 0);
                     asm volatile("s_nop 3" :: "v"(q) : "memory");                      // gfx950 wide-store hazard (kernels_up0.h)
                 }
             } else if (FULL || full) {
