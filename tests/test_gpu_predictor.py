@@ -136,3 +136,39 @@ def test_runs_on_different_streams_share_the_workspace_in_order():
             torch.cuda.synchronize()
             assert torch.equal(lg, ref)
             assert np.array_equal(o16, t16)
+
+
+def test_randomised_sliding_windows_are_bit_identical_to_the_host_restatement():
+    """A fixed-seed slice of scripts/gpu_fuzz_sliding_window.py: random image shapes (smaller and larger than the patch, Z = 1 / 2),
+    patch sizes, step sizes, mirror axes, fold counts, tile dtypes and a last (2, 1) / (1, 2) stage - device gather / mirror average /
+    float16 Gaussian aggregation against the host restatement fed with the same engine's per-tile logits, bit for bit."""
+    from totalsegmentator2d_amd import weights
+    rng = np.random.default_rng(5)
+    for t in range(10):
+        ns = int(rng.integers(2, 4))
+        feats = [32] + [int(rng.choice([32, 64])) for _ in range(ns - 1)]
+        strides = None
+        if rng.random() < 0.3:
+            strides = [(1, 1)] + [(2, 2)] * (ns - 2) + [[(2, 1), (1, 2)][int(rng.integers(0, 2))]]
+        arch = cases.unet(ns, feats, int(rng.integers(1, 9)), cin=int(rng.integers(1, 3)), nconv=1, strides=strides)
+        dy, dx = arch.divisors
+        patch = (dy * int(rng.integers(max(1, 16 // dy), 96 // dy + 1)), 32 * int(rng.integers(1, 5)))
+        shape = (int(rng.integers(1, 3)), int(rng.integers(5, 3 * patch[0])), int(rng.integers(5, 3 * patch[1])))
+        step = float(rng.choice([0.3, 0.5, 0.75, 1.0]))
+        mirror = [None, (0,), (1,), (0, 1)][int(rng.integers(0, 4))]
+        folds = int(rng.integers(1, 3))
+        order = ['float', 'half'][int(rng.integers(0, 2))]
+        blobs = [weights.pack_blob(arch, weights.synthetic_state_dict(arch, 900 + 7 * t + f)) for f in range(folds)]
+        data = prng.normal_f32(1000 + t, 999, (arch.input_channels,) + shape)
+        dev = HIPnnUNetPredictor(tile_step_size=step, use_mirroring=mirror is not None, tile_dtype=order)
+        dev.manual_initialization(arch, blobs, patch, inference_allowed_mirroring_axes=mirror)
+        try:
+            engines = dev.engines
+            host = HostLogicPredictor(network=lambda batch, fold: engines[fold].forward(np.ascontiguousarray(batch))[0],
+                                      tile_step_size=step, use_mirroring=mirror is not None, tile_dtype=order)
+            host.manual_initialization(arch, blobs, patch, inference_allowed_mirroring_axes=mirror)
+            a = dev.predict_logits_from_preprocessed_data(data).cpu().numpy()
+            b = host.predict_logits_from_preprocessed_data(data).cpu().numpy()
+        finally:
+            dev.close()
+        assert a.dtype == b.dtype == np.float16 and np.array_equal(a, b), (t, feats, strides, shape, patch, step, mirror, folds, order)
