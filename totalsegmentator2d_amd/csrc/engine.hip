@@ -1601,7 +1601,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             prof_kernel(e, "head");
             if (c.k == K_HEAD_MFMA) {      // matrix-core head (split / f16 modes)
                 ha.wph = wts + op.dev_wh; ha.oscale = wts + op.dev_ws;
-                const int bpw = 16;
+                const int bpw = 16;          // (4 ... 128 measured: 16 is as good as any - fewer, longer waves lose DRAM locality)
                 const long long nblk = ha.total / 32;
                 const unsigned gridm = (unsigned)((nblk + 4 * bpw - 1) / (4 * bpw));
                 if (f16) hipLaunchKernelGGL((head_mfma32<_Float16, 1>), dim3(gridm), dim3(256), 0, st, ha, bpw);
