@@ -54,6 +54,19 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get('TS2D_CPU_THREADS', 16))))
 
 
+def host_cpu_model() -> str:
+    """Model name of the host CPU (the baseline wanders 3.9 ... 5.3 slices/s between boxes of the pool: this says why)."""
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(arch, sd, budget_s: float = 20.0, check=None):
     """The oracle (torch-CPU restatement = the ATen kernels the reference CPU path runs), B = 1 per call like the
     reference, all host cores, on a bounded sample of the same workload.  `check` = (x, gpu logits)
@@ -75,7 +88,7 @@ def cpu_baseline(arch, sd, budget_s: float = 20.0, check=None):
         O.unet_forward(arch, sd, x)
         n += 1
     dt = time.time() - t0
-    return {'value': round(n / dt, 3), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
+    return {'value': round(n / dt, 3), 'unit': 'slices/s', 'cores': cores, 'cpu_model': host_cpu_model(), 'kind': 'port',
             'sample': f'{n} single-slice (B=1, no mirroring) 2x512x512 forwards of the same network, torch-CPU oracle, '
                       f'{torch.get_num_threads()} threads'}, err
 

@@ -422,6 +422,19 @@ def test_canonical_widths_on_extents_other_than_512(H, W, strides):
         assert np.abs(lg0 - ref).max() <= TOL and np.abs(lg0 - lg).max() <= 3e-5
         assert any(n.endswith('.up') for n in _level_kernels(e.op_kernels(), 2, 4))
         e.set_option('flex', 1)
+        # ... and with the 512-thread stride-2 kernel kept off the level-dividing tiles ("flex2" = 0: the one-image stride-2 kernel serves
+        # the ragged levels, as in round 4) - the other side of that switch, in both modes
+        s2_on = {n: k for n, k in _level_kernels(kern, 1, 5).items() if n.endswith('.c0') and n.startswith('enc')}
+        e.set_option('flex2', 0)
+        lg2, _ = e.forward(x, logits=True)
+        s2_off = {n: k for n, k in _level_kernels(e.op_kernels(), 1, 5).items() if n.endswith('.c0') and n.startswith('enc')}
+        assert np.abs(lg2 - ref).max() <= TOL and np.abs(lg2 - lg).max() <= 3e-5
+        assert s2_off != s2_on and not any(k in ('conv3x3s2_f16x3', 'conv_mfma_f32') for n, k in s2_off.items() if int(n[3]) <= 4), (s2_on, s2_off)
+        e.set_precision('f16')
+        lg16b, _ = e.forward(x, logits=True)
+        d = lg16b - ref16
+        assert np.abs(d).max() <= F16E_MAX and np.sqrt((d ** 2).mean()) <= F16E_RMS
+        e.set_option('flex2', 2)
         e.set_precision('f16')
         lg16, mk16 = e.forward(x, logits=True, mask=True)
         d = lg16 - ref16

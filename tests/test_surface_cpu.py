@@ -187,3 +187,10 @@ def test_combined_segmentation_equals_the_composed_label_masks(tmp_path):
     one = image.combine_segmentations([nrrd.Image(c.array, c.spacing, c.origin, c.direction, 1,
                                                   {k: v for k, v in c.meta.items() if not k.startswith('Segment1_')}, None)])
     assert one.components == 1 and np.array_equal(one.array, (c.array == 1).astype(np.uint8))
+    # the plane-major view vs what sitk.GetArrayFromImage hands out: contiguous() is the documented way to the interleaved bytes
+    cg = got.contiguous()
+    assert cg.array.flags['C_CONTIGUOUS'] and np.array_equal(cg.array, want) and cg.array.tobytes() == np.ascontiguousarray(want).tobytes()
+    assert cg.contiguous() is cg and cg.meta == got.meta
+    # no labelled member at all: an error, as sitk.Compose([]) is in the reference (ts2d/core/util/image.py:508)
+    with pytest.raises(ValueError, match='carries a label'):
+        image.combine_segmentations([nrrd.Image(c.array, c.spacing, c.origin, c.direction, 1, {}, None)])

@@ -1357,7 +1357,10 @@ int workspace_release(ts2d_engine* e, hipStream_t st) {
 bool workspace_is_mine(ts2d_engine* e) {
     if (!e->ws_external) return true;
     if (!e->d_ws || !e->ws_token) return false;
-    if (e->ws_busy && hipEventSynchronize(e->ws_event) != hipSuccess) return false;
+    // Another engine of the set may have ENQUEUED a run on a caller's stream that has not executed yet (its stamp is a stream-ordered
+    // memset): this engine's own event says nothing about that, so the token is read behind everything outstanding on the device.
+    // (A fresh host thread's current device is 0: select the engine's own first.)
+    if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
     uint32_t tok = 0;
     if (hipMemcpy(&tok, e->d_ws, sizeof(tok), hipMemcpyDeviceToHost) != hipSuccess) return false;
     return tok == e->ws_token;

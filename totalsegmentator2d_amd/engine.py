@@ -49,6 +49,7 @@ class Engine:
         self._last = None            # (weak reference to the input, logits?, mask?) of the last forward: debug_tensor re-runs it with
                                      # private buffers.  Weak: a production call must not pin the caller's batch in HBM.
         self._ran = False            # a forward has run on this handle (distinguishes "no forward yet" from "its input is gone")
+        self._ws_need = {}           # (B, H, W) -> workspace_bytes under the CURRENT mode / options / keep flag (cleared when those change)
         self._h = ctypes.c_void_p()
         d = _desc(arch)
         if blob is not None:
@@ -98,11 +99,13 @@ class Engine:
         one fp16 MFMA product, fp32 accumulate/statistics: BASELINE configs 3/5, outside the fp32 parity tolerance)."""
         m = {'exact': _lib.PRECISION_F32_EXACT, 'split': _lib.PRECISION_F32_SPLIT_F16X3, 'f16': _lib.PRECISION_F16}.get(mode, mode)
         _lib.check(self.lib.ts2d_engine_set_precision(self._h, int(m)), 'ts2d_engine_set_precision')
+        self._ws_need.clear()
 
     def set_option(self, name: str, value: int):
         """Kernel-dispatch option of this handle (C-ABI ts2d_engine_set_option, include/ts2d_engine.h lists the names): picks
         between two parity-tested kernels for the ops it names; takes effect at the next forward."""
         _lib.check(self.lib.ts2d_engine_set_option(self._h, name.encode(), int(value)), f'ts2d_engine_set_option({name})')
+        self._ws_need.clear()
 
     def set_tile_dtype(self, mode):
         """Blend order of :meth:`predict_tiled`: 'float' (reference CPU path: fp32 tile, one rounding into the half buffer;
@@ -114,6 +117,7 @@ class Engine:
         """One buffer per activation (C-ABI ts2d_engine_set_keep_activations) instead of liveness-based sharing; needed to read
         intermediate tensors back with :meth:`debug_tensor` (which switches it on itself and re-runs the last forward)."""
         _lib.check(self.lib.ts2d_engine_set_keep_activations(self._h, int(bool(on))), 'ts2d_engine_set_keep_activations')
+        self._ws_need.clear()
         self._keep = bool(on)
         self._auto_keep = False
 
@@ -122,10 +126,15 @@ class Engine:
         _lib.check(self.lib.ts2d_engine_reserve(self._h, B, H, W), 'ts2d_engine_reserve')
 
     def workspace_bytes(self, B: int, H: int, W: int) -> int:
-        """Bytes of activation workspace :meth:`reserve` would allocate for (B, H, W) in the current precision mode."""
-        n = ctypes.c_size_t()
-        _lib.check(self.lib.ts2d_engine_workspace_bytes(self._h, B, H, W, ctypes.byref(n)), 'ts2d_engine_workspace_bytes')
-        return int(n.value)
+        """Bytes of activation workspace :meth:`reserve` would allocate for (B, H, W) in the current precision mode.
+        (The C-ABI call re-plans every op; the answer is remembered until the mode, an option or the keep flag changes -
+        ``SubModelSet.forward_masks`` asks before every run.)"""
+        key = (int(B), int(H), int(W))
+        if key not in self._ws_need:
+            n = ctypes.c_size_t()
+            _lib.check(self.lib.ts2d_engine_workspace_bytes(self._h, B, H, W, ctypes.byref(n)), 'ts2d_engine_workspace_bytes')
+            self._ws_need[key] = int(n.value)
+        return self._ws_need[key]
 
     def set_workspace(self, dev_ptr: Optional[int], n_bytes: int = 0):
         """Run inside caller-owned device memory (C-ABI ts2d_engine_set_workspace; None: back to the engine's own allocation).
@@ -139,6 +148,7 @@ class Engine:
         K = self.arch.num_classes
         if self._auto_keep and not _debug_rerun:      # debug_tensor left private buffers behind: a production call returns to the shared arena
             _lib.check(self.lib.ts2d_engine_set_keep_activations(self._h, 0), 'ts2d_engine_set_keep_activations')
+            self._ws_need.clear()
             self._auto_keep = False
         self._ran = True
         try:
@@ -263,6 +273,7 @@ class Engine:
                                    "that a production call does not pin the batch): keep a reference to the object passed to forward(), "
                                    "or call keep_activations(True) before the forward")
             _lib.check(self.lib.ts2d_engine_set_keep_activations(self._h, 1), 'ts2d_engine_set_keep_activations')
+            self._ws_need.clear()
             self._auto_keep = True
             self.forward(x, logits=self._last[1], mask=self._last[2], _debug_rerun=True)
             if _is_torch(x):

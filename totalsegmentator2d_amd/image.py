@@ -281,6 +281,8 @@ def combine_segmentations(segs: Sequence[Image]) -> Image:
             vals.append(int(info['value']))
         plan.append((seg, vals))
     n = len(names)
+    if n == 0:          # (the reference's sitk.Compose([]) raises on an empty list as well)
+        raise ValueError('combine_segmentations: none of the segmentations carries a label (Segment*_Name metadata)')
     first = segs[0]
     if n == 1:
         seg, vals = next((s, v) for s, v in plan if v)

@@ -32,7 +32,13 @@ _NAMES = {'i1': 'signed char', 'u1': 'unsigned char', 'i2': 'short', 'u2': 'unsi
 @dataclass
 class Image:
     """Minimal stand-in for ``sitk.Image``: ``array`` is indexed like ``sitk.GetArrayFromImage`` -
-    ``[z, y, x]`` / ``[y, x]`` with a trailing component axis for vector images."""
+    ``[z, y, x]`` / ``[y, x]`` with a trailing component axis for vector images.
+
+    Memory layout: ``sitk.GetArrayFromImage`` always hands out a C-contiguous ``[..., component]`` array.  The segmentations this
+    package produces (``export.segmentation_to_image``, ``image.combine_segmentations``, ``image.restore_dimension``) are written
+    plane by plane and ``array`` is then the interleaved VIEW of a ``[component, ...]`` buffer: same shape, same values under
+    indexing, but ``array.flags.c_contiguous`` is False.  Code that reinterprets the memory (``.view(dtype)``, ``.ctypes.data``,
+    ``.data``, ``.tobytes()`` expecting interleaved bytes) must go through ``contiguous()`` first; ``nrrd.write`` does."""
     array: np.ndarray
     spacing: Tuple[float, ...]
     origin: Tuple[float, ...]
@@ -50,6 +56,12 @@ class Image:
         """(x, y[, z]) like ``sitk.Image.GetSize``."""
         shp = self.array.shape[:self.dimension]
         return tuple(int(s) for s in reversed(shp))
+
+    def contiguous(self) -> "Image":
+        """This image with a C-contiguous ``array`` (a copy only when ``array`` is a plane-major view)."""
+        if self.array.flags['C_CONTIGUOUS']:
+            return self
+        return Image(np.ascontiguousarray(self.array), self.spacing, self.origin, self.direction, self.components, dict(self.meta), self.space)
 
     def copy_geometry_from(self, other: "Image"):
         self.spacing, self.origin, self.direction, self.space = other.spacing, other.origin, other.direction, other.space

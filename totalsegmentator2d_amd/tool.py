@@ -71,9 +71,22 @@ class TS2D:
         self.close()
 
     def close(self):
+        pool, self._pool = getattr(self, '_pool', None), None
+        if pool is not None:
+            pool.shutdown(wait=True)
         for model in self.models.values():
             model.stop()
         self.models = {}
+
+    def _executor(self, n: int):
+        """One worker thread per sub-model for the life of this object (not five new threads per case)."""
+        pool = getattr(self, '_pool', None)
+        if pool is None or pool._max_workers < n:
+            from concurrent.futures import ThreadPoolExecutor
+            if pool is not None:
+                pool.shutdown(wait=True)
+            pool = self._pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix='ts2d-submodel')
+        return pool
 
     def predict(self, input: Union[nrrd.Image, str], collapse: bool = False, merge: bool = True) -> "TS2D.Result":
         if isinstance(input, str):
@@ -88,10 +101,16 @@ class TS2D:
         # releases the interpreter lock for the duration of a call
         prepared = {mid: self._prepare_model_input(mid, input, cache) for mid in order}
         if self.concurrent_models and len(order) > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=len(order)) as pool:
-                futs = {mid: pool.submit(self._apply_model, mid, prepared[mid], collapse) for mid in order}
-                done = {mid: f.result() for mid, f in futs.items()}      # (the first failure is raised, in sub-model order)
+            pool = self._executor(len(order))
+            futs = {mid: pool.submit(self._apply_model, mid, prepared[mid], collapse) for mid in order}
+            done = {}
+            try:
+                for mid in order:
+                    done[mid] = futs[mid].result()                       # (the first failure is raised, in sub-model order)
+            except BaseException:
+                for f in futs.values():                                  # sub-models that have not started yet are not run for a failed case
+                    f.cancel()
+                raise
         else:
             done = {mid: self._apply_model(mid, prepared[mid], collapse) for mid in order}
         for mid in order:
