@@ -11,6 +11,9 @@ import torch
 from totalsegmentator2d_amd.arch import UNetArch
 from totalsegmentator2d_amd import weights
 from totalsegmentator2d_amd.engine import Engine
+from totalsegmentator2d_amd import _lib as _L
+if os.environ.get('TS2D_AB_LIB'):      # script-only hook: time another build of the library (A/B across processes on one box)
+    _L.LIB_PATH = os.path.abspath(os.environ['TS2D_AB_LIB'])
 
 ap = argparse.ArgumentParser()
 ap.add_argument('variants', nargs='+')

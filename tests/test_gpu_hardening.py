@@ -149,3 +149,54 @@ def test_two_engines_on_two_devices_of_one_process():
                 a, _ = e0.forward(x, logits=True); b, _ = e1.forward(x, logits=True)
                 assert np.array_equal(a, b), mode
     assert np.array_equal(l0, l1) and np.array_equal(l1, l1b) and np.array_equal(m0, m1)
+
+
+@pytest.mark.parametrize('cin', [1, 2])
+def test_split_first_block_and_its_exact_fallback(cin):
+    """Round 6: the first block's K = 9 C contraction runs as ONE fp16 hi / lo split product (conv3x3_first_split: the input as
+    x / 4 = hi + lo, 22 bits) in the split and the 16-bit mode.  (a) Both sides of the "first_split" switch against the oracle's
+    enc0.c0, as its own kernel (fuse0 = 0, STORE form) and as the statistics-only pass in front of the fused second block.
+    (b) The precondition |x| < 262 016 must only cost speed: a tile whose patch holds a larger value - or one just below the
+    limit - is computed with the exact fp32 MFMAs (in-kernel, per tile) and the result follows the oracle all the same; the
+    reference feeds whatever float32 array its preprocessor produced (ts2d/core/inference/prediction_worker.py:206)."""
+    arch = cases.unet(3, (32, 64, 64), 4, cin=cin)
+    sd = weights.synthetic_state_dict(arch, 71)
+    blob = weights.pack_blob(arch, sd)
+    x = cases.make_input(arch, 2, 64, 96, 71)
+    xs = {'plain': x}
+    xb = x.copy()
+    xb[0, 0, 5, 7] = 3.0e5                      # beyond the split range: tile (0, 0) of image 0 falls back
+    xb[1, cin - 1, 40, 70] = -2.6e5             # just inside it (|x| / 4 = 65 000 < 65 504): stays on the split path
+    xb[1, 0, 63, 95] = 7.0e8                    # last pixel of the last tile
+    xs['outliers'] = xb
+    for tag, xin in xs.items():
+        ref, inter = O.unet_forward(arch, sd, xin, return_intermediates=True)
+        ref = ref.numpy()
+        want0 = inter['enc0.c0'].numpy()
+        got = {}
+        for fs in (1, 0):
+            with Engine(arch, blob, options={'first_split': fs, 'fuse0': 0}) as e:
+                e.set_profiling(True)
+                lg, _ = e.forward(xin)
+                assert (e.op_kernels()['enc0.c0'] == 'conv3x3_first_split') == bool(fs)
+                a0 = e.debug_tensor('enc0.c0')
+                assert np.isfinite(a0).all() and np.abs(a0 - want0).max() <= 3e-5, (tag, fs, float(np.abs(a0 - want0).max()))
+                assert _rel_err(lg, ref) <= 1e-4, (tag, fs, _rel_err(lg, ref))
+                got[fs] = a0
+                if tag != 'plain':               # (the raw conv output of such an input does not fit fp16 STORAGE: the 16-bit mode is not for it)
+                    continue
+                e.set_precision('f16')           # 16-bit mode: the same kernel with fp16 stores; enc0.c0 against ONE block of the 16-bit oracle
+                e.forward(xin)
+                assert (e.op_kernels()['enc0.c0'] == 'conv3x3_first_split') == bool(fs)
+                h0 = e.debug_tensor('enc0.c0')
+                w16 = O.layer_forward(arch, sd, 'enc0.c0', xin, emulate='f16', storage_view=True).numpy()
+                d = h0 - w16
+                assert np.isfinite(h0).all() and np.abs(d).max() <= 1e-2 and np.sqrt((d ** 2).mean()) <= 1e-4, (tag, fs, float(np.abs(d).max()))
+        assert np.abs(got[1] - got[0]).max() <= 2e-5
+        with Engine(arch, blob) as e:            # default: statistics-only pass (split product) + the recompute inside enc0.c1
+            e.set_profiling(True)
+            lg, _ = e.forward(xin)
+            if e.op_kernels().get('enc0.c0') == 'conv3x3_first_stats':
+                a1 = e.debug_tensor('enc0.c1')
+                assert np.abs(a1 - inter['enc0.c1'].numpy()).max() <= 3e-5, tag
+            assert _rel_err(lg, ref) <= 1e-4, (tag, _rel_err(lg, ref))

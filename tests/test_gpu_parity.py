@@ -366,17 +366,20 @@ def test_f16_first_block_on_every_complete_tile_shape(H, W, cin):
     sd, blob = blob_for(arch, 31)
     x = cases.make_input(arch, 2, H, W, 31)
     ref16 = O.unet_forward(arch, sd, x, emulate='f16')
-    with Engine(arch, blob) as e:
-        e.set_precision('f16')
-        e.set_profiling(True)
-        lg, _ = e.forward(x, logits=True)
-        assert e.op_kernels()['enc0.c0'] == 'conv3x3_first'
-        got = e.debug_tensor('enc0.c0')
-        want = O.layer_forward(arch, sd, 'enc0.c0', x, emulate='f16', storage_view=True).numpy()
-        assert got.shape == want.shape and np.isfinite(got).all()
-        assert _f16_layer_ok('enc0.c0', got, want), (float(np.abs(got - want).max()), float(np.sqrt(np.mean((got - want) ** 2))))
-        d = lg - ref16.numpy()
-        assert np.abs(d).max() <= F16E_MAX and np.sqrt((d ** 2).mean()) <= F16E_RMS
+    # both first-block kernels: conv3x3_first_split (round 6: the contraction as one fp16 hi / lo split product - the same transposed
+    # 16-byte-store epilogue) and, with "first_split" = 0, the exact-fp32 conv3x3_first
+    for fs, kname in ((1, 'conv3x3_first_split'), (0, 'conv3x3_first')):
+        with Engine(arch, blob, options={'first_split': fs}) as e:
+            e.set_precision('f16')
+            e.set_profiling(True)
+            lg, _ = e.forward(x, logits=True)
+            assert e.op_kernels()['enc0.c0'] == kname
+            got = e.debug_tensor('enc0.c0')
+            want = O.layer_forward(arch, sd, 'enc0.c0', x, emulate='f16', storage_view=True).numpy()
+            assert got.shape == want.shape and np.isfinite(got).all()
+            assert _f16_layer_ok('enc0.c0', got, want), (fs, float(np.abs(got - want).max()), float(np.sqrt(np.mean((got - want) ** 2))))
+            d = lg - ref16.numpy()
+            assert np.abs(d).max() <= F16E_MAX and np.sqrt((d ** 2).mean()) <= F16E_RMS
 
 
 def _level_kernels(kern, lo, hi):

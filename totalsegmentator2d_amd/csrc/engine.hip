@@ -132,6 +132,7 @@ struct Choice {
     int bn = 0;                 // output columns per workgroup
     int ksplit = 1;
     bool fused_stats = false;   // per-tile partial statistics come out of the kernel's epilogue (else stats_direct / splitk_reduce_stats)
+    int ppt = 1;                // ... partials per tile and channel (conv3x3_up0: one per wave)
     bool first_full = false;    // (K_FIRST*) complete one-image 256-pixel tiles: the persistent variant
     bool flex = false;          // (K_UPC / K_UPC_H / K_S2_V2) the level is no multiple of 8 x 32: the FLEX instance on the tile c.g
 };
@@ -170,6 +171,7 @@ struct ts2d_engine {
     bool use_h2 = true;           // "h2": 16-bit plain C -> C blocks on 16 x 32 tiles (0: conv3x3_h32); "h2_min": least channel count
     int h2_min = 64;
     bool use_uh2 = true;          // "uh2": 16-bit composed block on 16 x 32 tiles (0: conv3x3_upc_h)
+    bool use_first_split = true;  // "first_split": the first block's contraction as one fp16 hi / lo split product (kernels_first.h SPLIT; 0: exact fp32 MFMA)
     bool use_up0 = true;          // "up0": dedicated persistent kernel of the level-0 composed block (0: conv3x3_upc<32>)
     int u0seg = 0;                // "u0seg": tiles per workgroup segment of conv3x3_up0 (0: chosen from the grid; tests force segments that end inside an image)
     bool use_upq = true;          // "upq": 512-thread double-buffered variant of the composed block on 16 x 32 tiles (0: conv3x3_upc)
@@ -628,9 +630,11 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                     if (op.up0_ok) {       // fragment order of conv3x3_up0: lane = k-group (cb % 32) / 8, row co % 16
                         uint16_t* d0 = reinterpret_cast<uint16_t*>(out + op.dev_w0c);
                         const size_t f = ((size_t)(t >> 2) * 8 + (cb / 32) * 4 + (t & 3)) * 4;      // (parity, k-step) x [hi,lo][cb 2]
-                        const int ln = ((cb % 32) / 8) * 16 + co % 16;
-                        d0[((f + 0 + co / 16) * 64 + ln) * 8 + cb % 8] = hi;
-                        d0[((f + 2 + co / 16) * 64 + ln) * 8 + cb % 8] = lo;
+                        // MFMA block (co % 8) / 4, row 4 (co / 8) + co % 4: the lane that holds rows 4 g .. 4 g + 3 of both blocks owns channels 8 g .. 8 g + 7
+                        const int blk = (co % 8) / 4, row = 4 * (co / 8) + co % 4;
+                        const int ln = ((cb % 32) / 8) * 16 + row;
+                        d0[((f + 0 + blk) * 64 + ln) * 8 + cb % 8] = hi;
+                        d0[((f + 2 + blk) * 64 + ln) * 8 + cb % 8] = lo;
                     }
                 }
             for (int cs = 0; cs < cs_n; ++cs)
@@ -643,8 +647,9 @@ void pack_weights(const ts2d_engine* e, const float* blob, float* out) {
                     dk[((base + 2 + hh) * bn + co % bn) * 8 + cs % 8] = lo;
                     if (op.up0_ok) {
                         uint16_t* k0 = reinterpret_cast<uint16_t*>(out + op.dev_w0k);
-                        k0[((((size_t)tap * 2 + 0) * 4 + cs / 8) * 32 + co) * 8 + cs % 8] = hi;
-                        k0[((((size_t)tap * 2 + 1) * 4 + cs / 8) * 32 + co) * 8 + cs % 8] = lo;
+                        const int prow = ((co % 8) / 4) * 16 + 4 * (co / 8) + co % 4;      // (the same row permutation)
+                        k0[((((size_t)tap * 2 + 0) * 4 + cs / 8) * 32 + prow) * 8 + cs % 8] = hi;
+                        k0[((((size_t)tap * 2 + 1) * 4 + cs / 8) * 32 + prow) * 8 + cs % 8] = lo;
                     }
                 }
         });
@@ -1063,6 +1068,7 @@ Choice choose(const ts2d_engine* e, size_t oi, int B, int H, int W) {
         const Kern ck = composed_kernel(e, op, B, H, W);
         if (ck != K_NONE) {
             c.k = ck; c.fused_stats = true;
+            if (ck == K_UP0 && f16) c.ppt = 4;
             c.bn = op.cout % 64 == 0 ? 64 : 32;
             if (Ht % 8 || Wt % 32) { bool ok = false; c.g = tile_geom_upc(B, Ht, Wt, ok); c.flex = true; }
             else c.g = tile_fixed(B, Ht, Wt, (ck == K_UPQ || ck == K_UPC_H2) ? 16 : 8, 32, 1, 1);
@@ -1159,7 +1165,7 @@ size_t part_floats_needed(const ts2d_engine* e, int B, int H, int W) {
         const Op& op = e->ops[i];
         if (op.type != OP_CONV) continue;
         const Choice c = choose(e, i, B, H, W);
-        if (c.fused_stats) mx = std::max(mx, (size_t)B * c.g.tiles_x * c.g.tiles_y * op.cout * 4);      // (S, Q, K, n) per (tile, channel)
+        if (c.fused_stats) mx = std::max(mx, (size_t)B * c.g.tiles_x * c.g.tiles_y * c.ppt * op.cout * 4);      // (S, Q, K, n) per (tile, channel)
     }
     return mx;
 }
@@ -1421,7 +1427,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
         auto finalize = [&](int Ht, int Wt) -> int {
             Tensor& dst = e->tensors[op.dst];
             TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
-            launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y,
+            launch_finalize(B, op.cout, st, e->d_part, g.tiles_x * g.tiles_y * c.ppt,
                             op.cout, B, Ht * Wt, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
             HIP_TRY(hipGetLastError());
             return prof_end(e, st);
@@ -1446,6 +1452,9 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 fa.tr_off = (int)align_up(smem, 16);
                 smem = fa.tr_off + 4 * kFirstTr;
             }
+            // the K = 9 C contraction on the fp16 matrix path (hi / lo split input, one K = 54 product; kernels_first.h SPLIT): every mode but the exact one
+            const bool fsplit = e->use_first_split && e->precision != TS2D_PRECISION_F32_EXACT && c.first_full && nt == 1 && kp == 1;
+            if (fsplit) smem = (size_t)first_split_lds(P, f16 && c.k != K_FIRST_STATS);
             TRY(prof_begin(e, op.name, st)); prof_kernel(e, "conv3x3_first");
             // complete one-image 256-pixel tiles everywhere: persistent workgroups (4 per CU) with the next tile's patch in flight
             const bool first_full = c.first_full;
@@ -1453,9 +1462,16 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             if (c.k == K_FIRST_STATS) {        // statistics only; the block is recomputed inside the second one (implies first_full, nt == 1, kp == 1)
                 if (!first_full || !c.fused_stats) return fail(TS2D_ERR_INVALID, "internal: fused first block on a geometry without complete tiles");
                 prof_kernel(e, "conv3x3_first_stats");
-                if (f16) hipLaunchKernelGGL((conv3x3_first<1, 1, _Float16, true, false>), dim3(grid_first), dim3(kBlock), smem, st, fa);
+                if (fsplit) {
+                    if (f16) hipLaunchKernelGGL((conv3x3_first_split<_Float16, false>), dim3(grid_first), dim3(kBlock), smem, st, fa);
+                    else hipLaunchKernelGGL((conv3x3_first_split<float, false>), dim3(grid_first), dim3(kBlock), smem, st, fa);
+                } else if (f16) hipLaunchKernelGGL((conv3x3_first<1, 1, _Float16, true, false>), dim3(grid_first), dim3(kBlock), smem, st, fa);
                 else hipLaunchKernelGGL((conv3x3_first<1, 1, float, true, false>), dim3(grid_first), dim3(kBlock), smem, st, fa);
                 e->fused_away[0] = 1;
+            } else if (fsplit) {
+                prof_kernel(e, "conv3x3_first_split");
+                if (f16) hipLaunchKernelGGL((conv3x3_first_split<_Float16, true>), dim3(grid_first), dim3(kBlock), smem, st, fa);
+                else hipLaunchKernelGGL((conv3x3_first_split<float, true>), dim3(grid_first), dim3(kBlock), smem, st, fa);
             }
 #define TS2D_FIRST(NT_, KP_) do { \
                 if (first_full) { if (f16) hipLaunchKernelGGL((conv3x3_first<NT_, KP_, _Float16, true>), dim3(grid_first), dim3(kBlock), smem, st, fa); \
@@ -1513,7 +1529,7 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 if (f16) {
                     static std::atomic<uint64_t> done0h{0};
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_up0<_Float16, 1>), done0h));
-                    hipLaunchKernelGGL((conv3x3_up0<_Float16, 1>), dim3(u0.n_tiles / seg), dim3(kBlock), 9 * 4 * 512 + 4 * kResPS + 1536, st, u0);
+                    hipLaunchKernelGGL((conv3x3_up0<_Float16, 1>), dim3(u0.n_tiles / seg), dim3(kBlock), 9 * 4 * 512 + 8 * kResPS, st, u0);
                 } else {
                     static std::atomic<uint64_t> done0{0};
                     HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3_up0<float, 3>), done0));
@@ -1845,7 +1861,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
     struct B { const char* n; bool* p; };
     struct I { const char* n; int* p; int lo, hi; };
     const B bools[] = {{"h32", &e->use_h32}, {"one", &e->use_one}, {"s2v2", &e->use_s2v2}, {"q", &e->use_q}, {"h2", &e->use_h2},  {"uh2", &e->use_uh2},
-                       {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}, {"flex", &e->use_flex}};
+                       {"first_split", &e->use_first_split}, {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}, {"flex", &e->use_flex}};
     const I ints[] = {{"upq_min", &e->upq_min, 0, 1 << 20}, {"h2_min", &e->h2_min, 0, 1 << 20}, {"u0seg", &e->u0seg, 0, 1 << 20}, {"flex2", &e->use_flex2, 0, 2}};
     bool found = false;
     for (const B& b : bools) if (!strcmp(name, b.n)) { *b.p = value != 0; found = true; }
@@ -1853,7 +1869,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
         if (value < i.lo || value > i.hi) return fail(TS2D_ERR_INVALID, "option %s = %d out of range [%d, %d]", name, value, i.lo, i.hi);
         *i.p = value; found = true;
     }
-    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0 flex flex2)", name);
+    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0 flex flex2 first_split)", name);
     e->ws_precision = -1;         // which ops compose (and with it the activation plan) depends on the options: re-plan at the next reserve / forward
     ++e->opt_gen;
     return TS2D_OK;

@@ -17,6 +17,7 @@ struct FirstArgs {
     int B, C, H, W, Cout;
     int lgTH, lgTW, lgNIMG, tiles_x, tiles_y, n_mtiles, PH, PW;
     int tr_off;           // byte offset of the per-wave transpose regions in LDS (fp16 STORE variant on complete tiles: kFirstTr bytes per wave), or 0
+                          // (conv3x3_first_split lays its LDS out itself: first_split_lds)
 };
 
 constexpr int kFirstTrPitch = 80, kFirstTr = 32 * kFirstTrPitch;      // one M tile as [32 pixels][32 channels] halves, pixel pitch 80 B (bank-disjoint lane halves)
@@ -227,6 +228,230 @@ __global__ TS2D_PACKED_F32 __launch_bounds__(kBlock, FULL ? (NT == 1 ? 4 : 2) : 
         if (tid < NT * 32) stat_tile_store(red, 4, NT * 32, tid, a.part + ((size_t)(nimg0 * tpi + tin) * a.Cout + tid) * 4);
     }
     }   // tiles of this workgroup
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// conv3x3_first_split (round 6): the same block with its K = 9 C contraction on the fp16 matrix path instead of
+// exact-fp32 MFMA.  72 MFMAs of 64 cycles per tile made the statistics-only pass fp32-MFMA-bound (0.30 ms) and kept the 16-bit first block at
+// 0.41 ms for 1.2 GB.  C <= 2 input channels, Cout = 32, complete one-image 256-pixel tiles (the engine checks; everything else stays on
+// conv3x3_first), every precision mode but the exact one.
+//   * the input is split x / 4 = hi + lo while it is staged (two fp16 values = 22 bits, the operand precision of the rest of the net; the fixed
+//     pre-scale 2^-2 moves fp16's range to |x| < 262 016 - raw 16-bit intensities included - at an absolute error floor of 2^-23 for |x| < 0.5);
+//     the weights w S = whi + wlo, S = the power of two that puts max|w| into [2^11, 2^12), found by the kernel itself;
+//   * the three products x_hi w_hi + x_lo w_hi + x_hi w_lo are ONE K = 54 contraction padded to 64 = FOUR v_mfma_f32_32x32x16_f16 per 32 x 32
+//     block (128 matrix-pipe cycles instead of 576).  K order: quads Q_t = (x_hi c0, x_hi c1, x_lo c0, x_lo c1) of tap t against
+//     (w_hi c0, w_hi c1, w_hi c0, w_hi c1) - one ds_read_b64 of the split patch ([pixel] x 8 B) per tap - then pairs H_t = (x_hi c0, x_hi c1)
+//     against (w_lo c0, w_lo c1) - one ds_read_b32.  MFMA 0: lane half h reads Q_2h, Q_2h+1; MFMA 1: Q_4+2h, Q_5+2h; MFMA 2: H_4h .. H_4h+3;
+//     MFMA 3: h = 0: Q_8, H_8, zero; h = 1: the same (finite) data against zero weights.  No VALU work in the MFMA phase;
+//   * the two M tiles of a wave are computed and stored one after the other (16 accumulator registers live, four workgroups per CU);
+//   * a tile whose patch holds a value outside the range above (or a NaN / inf) is computed with the exact fp32 MFMAs straight from global
+//     memory (wave-uniform branch on an LDS flag raised while staging; slow and rare): the RESULT never depends on the precondition.
+// LDS: [P x 8 B split patch][2 flags][4 waves x 32 x (S, Q, K, n) statistics][fp16 STORE: 4 per-wave transpose regions of kFirstTr bytes].
+constexpr float kFirstLimit = 262016.f;          // 4 x 65504
+__host__ __device__ constexpr int first_split_red_off(int P) { return (P * 8 + 15) / 16 * 16 + 16; }
+__host__ __device__ constexpr int first_split_lds(int P, bool tr) { return first_split_red_off(P) + 4 * 32 * 16 + (tr ? 4 * kFirstTr : 0); }
+
+template <typename ST, bool STORE>
+__global__ TS2D_PACKED_F32 __launch_bounds__(kBlock, 4) void conv3x3_first_split(const FirstArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm8[];
+    typedef unsigned u32x4f __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2f __attribute__((ext_vector_type(2)));
+    const int TW = 1 << a.lgTW;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int P = a.PH * a.PW;
+    volatile int* const flag = reinterpret_cast<volatile int*>(sm8 + (P * 8 + 15) / 16 * 16);
+    float* const red = reinterpret_cast<float*>(sm8 + first_split_red_off(P));
+
+    // ---- weights: B operands of the four MFMAs (lane = output channel r, k half h), the scale that undoes S and the input pre-scale
+    u32x4f wsp[4];
+    float osc;
+    {
+        float wf[9][2], wmax = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                wf[tap][c] = c < a.C ? a.w[((size_t)r * a.C + c) * 9 + tap] : 0.f;
+                wmax = fmaxf(wmax, fabsf(wf[tap][c]));
+            }
+#pragma unroll
+        for (int d = 1; d < 32; d *= 2) wmax = fmaxf(wmax, __shfl_xor(wmax, d));
+        int e2 = 0;                                             // max|w| = m 2^e2, m in [0.5, 1): S = 2^(12 - e2)
+        (void)frexpf(wmax, &e2);
+        const bool sane = wmax > 0.f && wmax < 3.0e38f;         // (all-zero or non-finite weights: S = 1)
+        const float S = sane ? ldexpf(1.f, 12 - e2) : 1.f;
+        osc = sane ? ldexpf(1.f, e2 - 10) : 4.f;                // 4 / S
+        unsigned WH[9], WL[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            _Float16 hh[2], ll[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float ws = wf[tap][c] * S;
+                hh[c] = (_Float16)ws; ll[c] = (_Float16)(ws - (float)hh[c]);
+            }
+            WH[tap] = (unsigned)__builtin_bit_cast(unsigned short, hh[0]) | ((unsigned)__builtin_bit_cast(unsigned short, hh[1]) << 16);
+            WL[tap] = (unsigned)__builtin_bit_cast(unsigned short, ll[0]) | ((unsigned)__builtin_bit_cast(unsigned short, ll[1]) << 16);
+        }
+        wsp[0] = h ? u32x4f{WH[2], WH[2], WH[3], WH[3]} : u32x4f{WH[0], WH[0], WH[1], WH[1]};
+        wsp[1] = h ? u32x4f{WH[6], WH[6], WH[7], WH[7]} : u32x4f{WH[4], WH[4], WH[5], WH[5]};
+        wsp[2] = h ? u32x4f{WL[4], WL[5], WL[6], WL[7]} : u32x4f{WL[0], WL[1], WL[2], WL[3]};
+        wsp[3] = h ? u32x4f{0u, 0u, 0u, 0u} : u32x4f{WH[8], WH[8], WL[8], 0u};
+    }
+    const float bv = a.bias[r];
+    if (tid < 2) flag[tid] = 0;
+
+    // ---- staging plan (as conv3x3_first: element idx = tid + k * 256 of the plane-major patch; everything tile-independent computed once)
+    constexpr int MAXI = 4;
+    const float inv_pw = 1.0f / (float)a.PW;
+    int epk[MAXI], esp[MAXI];                                  // (py << 10 | px, bit 20 = channel) or -1; split-patch byte or -1
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+        const int idx = tid + k * kBlock;
+        const int c = idx >= P ? 1 : 0, pp = idx - c * P;
+        const int py = (int)(((float)pp + 0.5f) * inv_pw), px = pp - py * a.PW;
+        esp[k] = idx < 2 * P ? pp * 8 + c * 2 : -1;
+        epk[k] = (idx < 2 * P && c < a.C) ? (c << 20) | (py << 10) | px : -1;
+    }
+    auto patch_value = [&](int k, int mt_) -> float {
+        const int n_ = mt_ / tpi, tin_ = mt_ - n_ * tpi, tyi_ = tin_ / a.tiles_x, txi_ = tin_ - tyi_ * a.tiles_x;
+        const int y0_ = tyi_ << a.lgTH, x0_ = txi_ << a.lgTW;
+        const int py = (epk[k] >> 10) & 1023, px = epk[k] & 1023, c = epk[k] >> 20;
+        const int iy = y0_ - 1 + py, ix = x0_ - 1 + px;
+        float v = 0.f;
+        if (epk[k] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            v = a.x[(size_t)(n_ * a.C + c) * a.H * a.W + (unsigned)(iy * a.W + ix)];
+        return v;
+    };
+    // fragment addresses: tap t of a pixel sits ((t / 3) PW + t % 3) * 8 bytes behind it
+    int tq[4], th[4];
+    auto toff8 = [&](int t) { return ((t / 3) * a.PW + (t % 3)) * 8; };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        tq[j] = toff8((j >> 1) * 4 + 2 * h + (j & 1));             // MFMA j >> 1: Q_{4 (j >> 1) + 2 h + (j & 1)}
+        th[j] = toff8(4 * h + j);                                    // MFMA 2: H_{4 h + j}
+    }
+    const int t8 = toff8(8);
+    int apix8[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = 64 * w + 32 * mt + r;
+        apix8[mt] = ((m >> a.lgTW) * a.PW + (m & (TW - 1))) * 8;
+    }
+
+    float pvn[MAXI];
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) pvn[k] = patch_value(k, (int)blockIdx.x);
+    lds_barrier();                                              // the flags are clear
+    int par = 0;
+    for (int mtile = blockIdx.x; mtile < a.n_mtiles; mtile += gridDim.x, par ^= 1) {
+        const int n = mtile / tpi, tin = mtile - n * tpi;
+        const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
+        const int ty0 = tyi << a.lgTH, tx0 = txi << a.lgTW;
+        if (mtile != (int)blockIdx.x) lds_barrier();             // the previous tile's fragment reads are done
+        {
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < MAXI; ++k)
+                if (esp[k] >= 0) {
+                    const float xs = pvn[k] * 0.25f;
+                    const _Float16 xh = (_Float16)xs, xl = (_Float16)(xs - (float)xh);
+                    *reinterpret_cast<_Float16*>(sm8 + esp[k]) = xh;
+                    *reinterpret_cast<_Float16*>(sm8 + esp[k] + 4) = xl;
+                    bad = bad || !(fabsf(pvn[k]) < kFirstLimit);
+                }
+            if (bad) flag[par] = 1;
+        }
+        lds_barrier();
+        if (mtile + (int)gridDim.x < a.n_mtiles) {               // the next tile's patch: in flight during this tile's MFMAs and stores
+#pragma unroll
+            for (int k = 0; k < MAXI; ++k) pvn[k] = patch_value(k, mtile + (int)gridDim.x);
+        }
+        const bool exact_tile = __builtin_amdgcn_readfirstlane(flag[par]) != 0;       // (uniform: read behind the staging barrier)
+        if (tid == 0) flag[par ^ 1] = 0;                         // the next tile's flag: untouched until the next top-of-tile barrier
+        const float oscv = exact_tile ? 1.f : osc;               // (exact tile: fma(acc, 1, bias) = acc + bias, the unsplit epilogue bit for bit)
+
+        const size_t img_el = (size_t)a.H * a.W * 32;
+        const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)n * img_el, 0, (int)(img_el * sizeof(ST)), 0x00020000);
+        float ss = 0.f, qq = 0.f, kv = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            if (!exact_tile) {
+                const unsigned char* xb = sm8 + apix8[mt];       // the lane's pixel of M tile mt
+                u32x4f fa[4];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const u32x2f q0 = *reinterpret_cast<const u32x2f*>(xb + tq[2 * m]), q1 = *reinterpret_cast<const u32x2f*>(xb + tq[2 * m + 1]);
+                    fa[m] = u32x4f{q0[0], q0[1], q1[0], q1[1]};
+                }
+                fa[2] = u32x4f{*reinterpret_cast<const unsigned*>(xb + th[0]), *reinterpret_cast<const unsigned*>(xb + th[1]),
+                               *reinterpret_cast<const unsigned*>(xb + th[2]), *reinterpret_cast<const unsigned*>(xb + th[3])};
+                const u32x2f q8 = *reinterpret_cast<const u32x2f*>(xb + t8);
+                fa[3] = u32x4f{q8[0], q8[1], q8[0], 0u};
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[m]), __builtin_bit_cast(half8, wsp[m]), acc, 0, 0, 0);
+            } else {                                             // out-of-range input in this tile: exact fp32 MFMAs, operands straight from global memory
+                const int m = 64 * w + 32 * mt + r;
+                const int oy = ty0 + (m >> a.lgTW), ox = tx0 + (m & (TW - 1));
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+                    float av = 0.f, wv = 0.f;
+                    if (h < a.C) {
+                        wv = a.w[((size_t)r * a.C + h) * 9 + tap];
+                        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) av = a.x[((size_t)(n * a.C + h) * a.H + iy) * a.W + ix];
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc, 0, 0, 0);
+                }
+            }
+            if (mt == 0) kv = stat_pivot(round_act<ST>(__builtin_fmaf(acc[0], oscv, bv)));      // shifted statistics (kernels.h)
+            if constexpr (STORE && sizeof(ST) == 2) {
+                // 16-bit storage: the M tile = 2 KB of contiguous NHWC output, transposed through a per-wave LDS region ([pixel][channel] halves;
+                // same-wave LDS operations execute in order: no barrier) and stored as 2 x 16 bytes per lane (conv3x3_first, round 5)
+                unsigned char* tw = sm8 + first_split_red_off(P) + 4 * 32 * 16 + w * kFirstTr;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int px = 4 * h + (i & 3) + 8 * (i >> 2);
+                    const _Float16 hv = (_Float16)__builtin_fmaf(acc[i], oscv, bv);
+                    *reinterpret_cast<_Float16*>(tw + px * kFirstTrPitch + r * 2) = hv;
+                    const float d = (float)hv - kv;                                       // statistics of what is stored
+                    ss += d; qq = __builtin_fmaf(d, d, qq);
+                }
+                const int m0 = 64 * w + 32 * mt;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int piece = k * 64 + lane;                                        // 16-byte piece of the 2 KB: pixel piece / 4, part piece % 4
+                    const int m = m0 + (piece >> 2);
+                    const unsigned off = (unsigned)((((ty0 + (m >> a.lgTW)) * a.W + tx0 + (m & (TW - 1))) * 32) * 2 + (piece & 3) * 16);
+                    const u32x4f q = *reinterpret_cast<const u32x4f*>(tw + (piece >> 2) * kFirstTrPitch + (piece & 3) * 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(q, rsd, off, 0, 0);
+                    asm volatile("s_nop 3" :: "v"(q) : "memory");                          // gfx950 wide-store hazard (kernels_up0.h)
+                }
+            } else {
+                const int m0 = 64 * w + 32 * mt + 4 * h;
+                const int oy = ty0 + (m0 >> a.lgTW), ox = tx0 + (m0 & (TW - 1));
+                const unsigned voff = (unsigned)(((oy * a.W + ox) * 32 + r) * (int)sizeof(ST));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rowoff = (i & 3) + 8 * (i >> 2);
+                    const unsigned soff = (unsigned)((((rowoff & (TW - 1)) + (rowoff >> a.lgTW) * a.W) * 32) * (int)sizeof(ST));
+                    const float v = __builtin_fmaf(acc[i], oscv, bv);
+                    if constexpr (STORE) buffer_store_act<ST>(v, rsd, voff, soff);
+                    const float d = round_act<ST>(v) - kv;
+                    ss += d; qq = __builtin_fmaf(d, d, qq);
+                }
+            }
+        }
+        ss += __shfl_xor(ss, 32); qq += __shfl_xor(qq, 32);
+        if (h == 0) stat_wave_put(red, w * 32 + r, ss, qq, kv, 64.f);
+        lds_barrier();
+        if (tid < 32) stat_tile_store(red, 4, 32, tid, a.part + ((size_t)(n * tpi + tin) * 32 + tid) * 4);
+    }
 }
 
 }  // namespace ts2d

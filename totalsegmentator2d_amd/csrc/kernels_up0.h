@@ -16,6 +16,14 @@
 // LDS images as in kernels_res32.h (k-group-major planes of 16-byte slots, plane strides multiples of 256 B).  Skip patch columns are
 // stored even-first / odd-second (the stride-2 pixel walk of a parity class is then a walk over consecutive slots); the 16 coarse
 // planes (6 x 18 pixels) sit two per skip-plane window, clear of the 12 spare slots that hold the statistics scratch.
+// Round 6:
+//   * channel order of the MFMA rows permuted on the host (row 4 g + i of block cb = channel 8 g + 4 cb + i): a lane holds EIGHT consecutive channels
+//     of its pixel - one 16-byte store per pixel in the 16-bit mode (was two 8-byte pieces of a 64-byte record), 32 contiguous bytes in fp32;
+//   * the statistics leave the tile loop's serial section: pivot K = the interior bias (no broadcast, no dependency on the tile's data), each WAVE
+//     writes its own partial (S, Q, K, 64) per channel straight to global memory (4 partials per tile; finalize_stats combines any number) - the LDS
+//     scratch, the barrier-coupled merge by wave 0 and its global store are gone;
+//   * 16-bit mode: the coarse planes have their own LDS region (the workgroup's 62 KB still fit twice), so a tile needs TWO barriers instead of four
+//     (behind each conversion): a wave that is done with a tile starts converting the next one without waiting for the slowest wave's epilogue.
 #pragma once
 #include <type_traits>
 #include "kernels_res32.h"
@@ -30,6 +38,7 @@ struct Up0Args {
     const float* bvar;     // [9 = (ry, rx)][32] bias variants (kernels_upc.h)
     const float* oscale;   // 1 / (common power-of-two pre-scale of both images)
     void* dst; float* part;       // raw NHWC [B, H, W, 32] output; InstanceNorm partials [n][tile (column-major)][32] x (S, Q, K, n)
+                                  // (16-bit mode: [n][tile][wave 4][32] - one partial per wave)
     int B, H, W;           // output geometry: H % 8 == 0, W % 32 == 0
     int tiles_x, tiles_y, n_tiles, seg;      // as Res32Args
     float slope;
@@ -76,9 +85,11 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
         }
     }
     unsigned char* sP = smem8 + WB;                        // patch region: skip planes [part][g][slot] x 16 B / coarse planes
-    auto scratch = [&](int ww, int gg) -> float* {
-        if (NPP == 2) return reinterpret_cast<float*>(sP + (2 * ww + (gg >> 1)) * kResPS + kResP * 16 + (gg & 1) * 96);
-        return reinterpret_cast<float*>(sP + NPP * 4 * kResPS + (ww * 4 + gg) * 96);
+    constexpr int CO = NPP == 2 ? 0 : 4 * kResPS;          // coarse planes: on the skip planes (split mode: the two workgroups of a CU use all 160 KB) / behind them
+    constexpr bool TWO_BARRIERS = NPP == 1;
+    constexpr bool DIRECT = NPP == 1;                      // per-wave partials straight to global memory (split mode: measured 3 % SLOWER than the LDS merge - kept there)
+    auto scratch = [&](int ww, int gg) -> float* {         // !DIRECT: per wave and k-group row [2 cb][3 = S, Q, K][4 channels] floats in the 12 spare slots of a plane
+        return reinterpret_cast<float*>(sP + (2 * ww + (gg >> 1)) * kResPS + kResP * 16 + (gg & 1) * 96);
     };
 
     // ---- skip staging plan: unit it = patch pixel p = 64 it + 16 w + 2 (lane & 7) + (lane >> 5), channel group sg: a wave instruction
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
     }
     const bool last_c = 8 * (w + 4 * (NUC - 1)) + (lane & 7) < 108;
     // coarse plane (part, ks, g) at (part * 2 + ks) * WIN + (g >> 1) * kResPS + (g & 1) * kU0CP
-    const int lwc = (cg >> 2) * WIN + ((cg >> 1) & 1) * kResPS + (cg & 1) * kU0CP + (8 * w + (lane & 7)) * 16;      // unit it: + 512 it; lo part: + 2 WIN
+    const int lwc = CO + (cg >> 2) * WIN + ((cg >> 1) & 1) * kResPS + (cg & 1) * kU0CP + (8 * w + (lane & 7)) * 16;      // unit it: + 512 it; lo part: + 2 WIN
 
     const size_t simg = (size_t)a.H * a.W * 32 * sizeof(ST), cimg = (size_t)Hc * Wc * 64 * sizeof(ST);
     const auto rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.xs)) + (size_t)n * simg, 0, (int)simg, 0x00020000);
@@ -148,15 +159,15 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
 
     // ---- lane constants of the MFMA phases and the epilogue
     const int wbase = g * 512 + j * 16;                                                     // resident weight fragment
-    const int cbase = WB + (g >> 1) * kResPS + (g & 1) * kU0CP + (pA * 18 + j + pB) * 16;    // coarse fragment: + q * WIN + ((I + dI) * 18 + dJ) * 16
+    const int cbase = WB + CO + (g >> 1) * kResPS + (g & 1) * kU0CP + (pA * 18 + j + pB) * 16;    // coarse fragment: + q * WIN + ((I + dI) * 18 + dJ) * 16
     const int sbase = WB + g * kResPS + j * 16;                                             // skip fragment: + tap term (wave-uniform) + part * 4 PS + 2 I * 34 * 16
     const float oscale = *a.oscale;
     float bv[2][4];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bv[cb][i] = a.bvar[4 * 32 + cb * 16 + 4 * g + i];
-    const unsigned vst = (unsigned)(((2 * j + pB) * 32 + 4 * g) * (int)sizeof(ST));
+        for (int i = 0; i < 4; ++i) bv[cb][i] = a.bvar[4 * 32 + 8 * g + 4 * cb + i];      // (row 4 g + i of MFMA block cb = channel 8 g + 4 cb + i: pack_weights)
+    const unsigned vst = (unsigned)(((2 * j + pB) * 32 + 8 * g) * (int)sizeof(ST));
     const _Float16 slope_h = (_Float16)a.slope;
     const unsigned slope2 = (unsigned)__builtin_bit_cast(unsigned short, slope_h) * 0x10001u;
     const auto rsd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(a.dst) + (size_t)n * simg, 0, (int)simg, 0x00020000);
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
         }
         __builtin_amdgcn_s_setprio(0);
         TS2D_STAMP(2)
-        lds_barrier();                                     // every wave is done with the coarse planes
+        if constexpr (!TWO_BARRIERS) lds_barrier();        // every wave is done with the coarse planes (16-bit mode: they have their own region)
         TS2D_STAMP(3)
 
         // ============================================================ C: skip patch -> LDS
@@ -341,9 +352,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     ss[cb][i] = 0.f; qq[cb][i] = 0.f;
-                    float v0 = __builtin_fmaf(acc[cb][0][i], oscale, bv[cb][i]);
-                    if constexpr (sizeof(ST) != 4) v0 = (float)(_Float16)v0;
-                    kv[cb][i] = __shfl(v0, lane & 48);      // pivot of the shifted statistics (kernels.h): any finite value near the data
+                    // pivot of the shifted statistics (kernels.h): any finite value near the data.  DIRECT: the interior bias; else a value of the tile
+                    if constexpr (DIRECT) kv[cb][i] = bv[cb][i];
+                    else kv[cb][i] = __shfl(__builtin_fmaf(acc[cb][0][i], oscale, bv[cb][i]), lane & 48);
                 }
             const unsigned tile_off = (unsigned)((((tyi * 8 + pA) * a.W + txi * 32) * 32) * (int)sizeof(ST));      // scalar
             f32x4 b4[4][2];
@@ -355,36 +366,41 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
                     if constexpr (BORDER) {
                         const int X = txi * 32 + 2 * j + pB, Y = tyi * 8 + 2 * pb + pA;
                         const int rx = X == 0 ? 0 : (X == a.W - 1 ? 2 : 1), ry = Y == 0 ? 0 : (Y == a.H - 1 ? 2 : 1);
-                        b4[pb][cb] = *reinterpret_cast<const f32x4*>(a.bvar + (ry * 3 + rx) * 32 + cb * 16 + 4 * g);
+                        b4[pb][cb] = *reinterpret_cast<const f32x4*>(a.bvar + (ry * 3 + rx) * 32 + 8 * g + 4 * cb);
                     }
                 }
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb)
+            for (int pb = 0; pb < 4; ++pb) {
+                const unsigned soff = tile_off + (unsigned)(((2 * pb * a.W) * 32) * (int)sizeof(ST));
+                f32x4 v[2];
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    const unsigned soff = tile_off + (unsigned)(((2 * pb * a.W) * 32 + cb * 16) * (int)sizeof(ST));
-                    f32x4 v;
+                for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[cb][pb][i], oscale, b4[pb][cb][i]);
-                    // wide-store hazard of gfx950 (found with the round-2 form of conv3x3_res32): a VALU write to the data registers of a 128-bit
-                    // buffer store two instructions behind it reaches the stored data (last dword, lanes 12-15 of each lane row) - hipcc's one
-                    // wait state is not enough, and with an SGPR soffset it inserts none.  The offset rides in the VGPR and wait states follow the store
-                    if constexpr (sizeof(ST) == 4) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsd, vst + soff, 0, kU0NT);
-                    } else {
-                        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        half4 hv;
+                    for (int i = 0; i < 4; ++i) v[cb][i] = __builtin_fmaf(acc[cb][pb][i], oscale, b4[pb][cb][i]);
+                // wide-store hazard of gfx950 (found with the round-2 form of conv3x3_res32): a VALU write to the data registers of a 128-bit
+                // buffer store two instructions behind it reaches the stored data (last dword, lanes 12-15 of each lane row) - hipcc's one
+                // wait state is not enough, and with an SGPR soffset it inserts none.  The offset rides in the VGPR and wait states follow the store
+                if constexpr (sizeof(ST) == 4) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[0]), rsd, vst + soff, 0, kU0NT);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[1]), rsd, vst + soff + 16, 0, kU0NT);
+                    asm volatile("s_nop 3" :: "v"(v[0]), "v"(v[1]) : "memory");      // (v as operands: their registers stay allocated up to the wait states)
+                } else {
+                    half8 hv;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { hv[i] = (_Float16)v[i]; v[i] = (float)hv[i]; }
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rsd, vst + soff, 0, kU0NT);
-                    }
-                    asm volatile("s_nop 3" :: "v"(v) : "memory");      // (v as an operand: its registers stay allocated up to the wait states -
-                                                                       //  without it the scheduler moved VALU work in between and reused them 3 instructions behind the store)
+                    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { const float d = v[i] - kv[cb][i]; ss[cb][i] += d; qq[cb][i] = __builtin_fmaf(d, d, qq[cb][i]); }
+                        for (int i = 0; i < 4; ++i) { hv[4 * cb + i] = (_Float16)v[cb][i]; v[cb][i] = (float)hv[4 * cb + i]; }
+                    const u32x4 hq = __builtin_bit_cast(u32x4, hv);
+                    __builtin_amdgcn_raw_buffer_store_b128(hq, rsd, vst + soff, 0, kU0NT);      // the lane's 8 channels of this pixel: 16 bytes
+                    asm volatile("s_nop 3" :: "v"(hq) : "memory");
                 }
-            float* sc4 = scratch(w, g);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float d = v[cb][i] - kv[cb][i]; ss[cb][i] += d; qq[cb][i] = __builtin_fmaf(d, d, qq[cb][i]); }
+            }
+            // the wave's partial per channel: 16 lanes (j) -> lane j = 0 of each k-group row, then straight to global memory
+            float* pw = a.part + ((((size_t)n * tpi + (size_t)(t - n * tpi)) * 4 + w) * 32 + 8 * g) * 4;      // (DIRECT)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
@@ -396,28 +412,45 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_up0(const Up0Args a) {
 #undef TS2D_ROR_ADD
                     ss[cb][i] = s; qq[cb][i] = q;
                 }
-                if (j == 0) {
-                    *reinterpret_cast<f32x4*>(sc4 + cb * 12) = f32x4{ss[cb][0], ss[cb][1], ss[cb][2], ss[cb][3]};
-                    *reinterpret_cast<f32x4*>(sc4 + cb * 12 + 4) = f32x4{qq[cb][0], qq[cb][1], qq[cb][2], qq[cb][3]};
-                    *reinterpret_cast<f32x4*>(sc4 + cb * 12 + 8) = f32x4{kv[cb][0], kv[cb][1], kv[cb][2], kv[cb][3]};
+            }
+            if (j == 0) {
+                if constexpr (DIRECT) {
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 pq = f32x4{ss[cb][i], qq[cb][i], kv[cb][i], 64.f};
+                            *reinterpret_cast<f32x4*>(pw + (4 * cb + i) * 4) = pq;
+                            asm volatile("s_nop 3" :: "v"(pq) : "memory");
+                        }
+                } else {
+                    float* sc4 = scratch(w, g);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        *reinterpret_cast<f32x4*>(sc4 + cb * 12) = f32x4{ss[cb][0], ss[cb][1], ss[cb][2], ss[cb][3]};
+                        *reinterpret_cast<f32x4*>(sc4 + cb * 12 + 4) = f32x4{qq[cb][0], qq[cb][1], qq[cb][2], qq[cb][3]};
+                        *reinterpret_cast<f32x4*>(sc4 + cb * 12 + 8) = f32x4{kv[cb][0], kv[cb][1], kv[cb][2], kv[cb][3]};
+                    }
                 }
             }
         };
         if (edge) epilogue(std::true_type{}); else epilogue(std::false_type{});
-        lds_barrier();                                     // every wave is done with the skip planes; the scratch is complete
-        if (tid < 32) {                                    // tile partial: fixed order over the 4 waves, rebased onto wave 0's pivot
-            const int co = tid, cb = co >> 4, gg = (co >> 2) & 3, i = co & 3;
-            const float* s0 = scratch(0, gg) + cb * 12 + i;
-            f32x4 acc4 = f32x4{s0[0], s0[4], s0[8], 64.f};
+        if constexpr (!TWO_BARRIERS) lds_barrier();        // every wave is done with the skip planes (16-bit mode: the next conversion writes the coarse region)
+        if constexpr (!DIRECT) {
+            if (tid < 32) {                                // tile partial: fixed order over the 4 waves, rebased onto wave 0's pivot; channel co = 8 gg + 4 cb + i
+                const int co = tid, gg = co >> 3, cb = (co >> 2) & 1, i = co & 3;
+                const float* s0 = scratch(0, gg) + cb * 12 + i;
+                f32x4 acc4 = f32x4{s0[0], s0[4], s0[8], 64.f};
 #pragma unroll
-            for (int ww = 1; ww < 4; ++ww) {
-                const float* sw_ = scratch(ww, gg) + cb * 12 + i;
-                const float d = sw_[8] - acc4[2];
-                acc4[1] += sw_[4] + d * (2.f * sw_[0] + 64.f * d);
-                acc4[0] += sw_[0] + 64.f * d;
-                acc4[3] += 64.f;
+                for (int ww = 1; ww < 4; ++ww) {
+                    const float* sw_ = scratch(ww, gg) + cb * 12 + i;
+                    const float d = sw_[8] - acc4[2];
+                    acc4[1] += sw_[4] + d * (2.f * sw_[0] + 64.f * d);
+                    acc4[0] += sw_[0] + 64.f * d;
+                    acc4[3] += 64.f;
+                }
+                *reinterpret_cast<f32x4*>(a.part + (((size_t)n * tpi + (t - n * tpi)) * 32 + co) * 4) = acc4;
             }
-            *reinterpret_cast<f32x4*>(a.part + (((size_t)n * tpi + (t - n * tpi)) * 32 + co) * 4) = acc4;
         }
         txi = ntx; tyi = nty;
         TS2D_STAMP(6)
