@@ -88,13 +88,21 @@ int ts2d_engine_set_precision(ts2d_engine* e, int mode);
 /* Kernel-dispatch options (ABI 6; replaces the TS2D_* environment switches of ABI <= 5 - a product library must not change kernels
  * because of its caller's environment).  Several ops have two complete, parity-tested kernels (e.g. the decoder entry composed
  * with its ConvTranspose2d, or as two kernels); an option picks one for THIS handle, takes effect at the next reserve / forward and
- * never changes results beyond fp32 summation order (the parity tests run both sides of every switch).  Names (value 0 / 1 unless noted):
+ * never changes results beyond fp32 summation order (every switch has a parity test on each of its sides).  Names (value 0 / 1 unless noted):
  *   "upc" composed decoder entry | "upq" its 512-thread variant | "upq_min" (int) least coarse channels for it | "up0" dedicated
  *   level-0 composed kernel | "u0seg" (int) its tiles per workgroup segment, 0 = automatic | "q" persistent 16x32-tile stride-1 kernel |
  *   "one" one-image-tile kernels | "res" resident-weight 32 -> 32 kernel | "fuse0" first block recomputed inside the second |
  *   "s2v2" 512-thread stride-2 kernel | "h32", "h2", "h2_min" (int), "uh2": the 16-bit mode's variants | "flex" the composed decoder
  *   entry on tiles that follow the level's extent where it is no multiple of 8 x 32 pixels (0: transposed conv + conv there) |
- *   "flex2" (int) the 512-thread stride-2 kernel on tiles that divide such a level (0: off, 1: 16-bit mode only, 2: every mode).
+ *   "flex2" (int) the 512-thread stride-2 kernel on tiles that divide such a level (0: off, 1: 16-bit mode only, 2: every mode) |
+ *   "first_split" the first block's K = 9 C contraction as one fp16 hi / lo split product (0: exact fp32 MFMA) |
+ *   "sbk" the small-batch dispatch: where the preferred kernel of an op would launch fewer workgroups than the device has CUs (the
+ *   <= 32 x 32 levels of one ... eight slices - what TS2D.predict and the reference's B = 1 loop run), K is split over more workgroups
+ *   (deterministic two-phase reduction) and a composed decoder entry runs as transposed conv + conv.  With "sbk" on (the default) a
+ *   slice's result is bit-identical between two batches only if both take the same path (e.g. any two batches >= 32 of the canonical
+ *   net); across paths it agrees to fp32 summation order (3e-5 on the logits).  The same batch always reproduces its bits.
+ * Most of these have had one measured winner for rounds ("q", "res", "one", "s2v2", "h32", "upq", "up0" ...): they are test scaffolding -
+ * the way the parity suite reaches the second kernel of an op - not tuning knobs of the product.
  * Unknown names and out-of-range values return TS2D_ERR_INVALID.  The reference has no counterpart (one code path through torch:
  * ts2d/core/inference/prediction_worker.py:209); the callers are this repo's tests and A/B scripts. */
 int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value);

@@ -10,7 +10,9 @@ if os.environ.get('TS2D_AB_LIB'):      # script-only hook: time another build of
     _L.LIB_PATH = os.path.abspath(os.environ['TS2D_AB_LIB'])
 
 a = UNetArch.canonical(num_classes=18)
-e = Engine(a, weights.pack_blob(a, weights.synthetic_state_dict(a, 1)))
+opts = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in os.environ.get('SB_OPTS', '').split(',') if kv}
+e = Engine(a, weights.pack_blob(a, weights.synthetic_state_dict(a, 1)), options=opts)
+print('options', opts, flush=True)
 for mode in ('split', 'f16'):
     e.set_precision(mode)
     for B in (1, 2, 4, 8, 16):
@@ -18,7 +20,7 @@ for mode in ('split', 'f16'):
         e.reserve(B, 512, 512)
         def fwd():
             e.forward(x, logits=True, mask=False); torch.cuda.synchronize()
-        fwd(); t = time.time(); n = 20
+        fwd(); fwd(); t = time.time(); n = 50
         for _ in range(n): fwd()
         wall = (time.time() - t) / n * 1e3
         e.set_profiling(True); e.forward(x, logits=True, mask=False); torch.cuda.synchronize()

@@ -10,7 +10,9 @@ if os.environ.get('TS2D_AB_LIB'):
     _L.LIB_PATH = os.path.abspath(os.environ['TS2D_AB_LIB'])
 Bs = [int(v) for v in sys.argv[1:]] or [1, 8]
 a = UNetArch.canonical(num_classes=18)
-e = Engine(a, weights.pack_blob(a, weights.synthetic_state_dict(a, 1)))
+opts = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in os.environ.get('SB_OPTS', '').split(',') if kv}
+e = Engine(a, weights.pack_blob(a, weights.synthetic_state_dict(a, 1)), options=opts)
+print('options', opts, flush=True)
 for mode in ('split', 'f16'):
     e.set_precision(mode)
     for B in Bs:

@@ -11,6 +11,18 @@ from totalsegmentator2d_amd.arch import UNetArch
 from totalsegmentator2d_amd.engine import Engine, unpack_mask
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _large_batch_kernels_at_small_b():
+    """The tests of this module address the kernels a full batch runs on (persistent / composed / 512-thread) by driving them with one
+    to three slices; round 6's small-batch dispatch ("sbk": split-K and the two-kernel decoder entry where those kernels would leave
+    most CUs idle) would take such batches elsewhere.  It is switched off here and has its own module (tests/test_gpu_small_batch.py)."""
+    from totalsegmentator2d_amd.engine import Engine as _E
+    old = dict(_E.default_options)
+    _E.default_options = {**old, 'sbk': 0}
+    yield
+    _E.default_options = old
 TOL = 1e-4
 
 

@@ -32,7 +32,9 @@ def test_rank_blocks_equal_the_single_rank_result():
     arch = cases.unet(4, (32, 64, 64, 128), 6)
     _, blob = blob_for(arch, 51)
     shape, total = (2, 64, 96), 23
-    with Engine(arch, blob) as e:
+    # ("sbk" = 0: the kernels of full batches at any batch size - with the small-batch dispatch of round 6 a slice is bit-identical
+    #  only between batches that take the same path; its cross-regime bound is tests/test_gpu_small_batch.py's)
+    with Engine(arch, blob, options={'sbk': 0}) as e:
         lo, hi, whole, _ = parallel.run_slice_stream(e, 11, total, 0, 1, shape, batch=8)
         assert (lo, hi) == (0, total) and whole.shape == (total, 6, 64, 3)
         got = []
@@ -47,6 +49,14 @@ def test_rank_blocks_equal_the_single_rank_result():
         torch.cuda.synchronize()
         assert torch.equal(mk, whole[4:6])
         assert (lg > 1.5 * 2.0 ** -24).any() and (lg <= 1.5 * 2.0 ** -24).any()
+    with Engine(arch, blob) as e:                  # product default: blocks of another batch size may differ in bits that sit at the threshold only
+        _, _, whole1, _ = parallel.run_slice_stream(e, 11, total, 0, 1, shape, batch=8)
+        for r in range(3):
+            lo, hi, m, _ = parallel.run_slice_stream(e, 11, total, r, 3, shape, batch=5)
+            diff = (m ^ whole1[lo:hi]).to(torch.int64) & 0xFFFFFFFF
+            nbits = sum(int(((diff >> b) & 1).sum()) for b in range(32))
+            assert nbits <= max(4, m.numel() * 32 // 20000), nbits
+        assert int(((whole1 ^ whole).to(torch.int64) & 0xFFFFFFFF != 0).sum()) <= max(4, whole.numel() // 20000)
 
 
 def test_bench_config4_mode_with_the_rccl_path_rehearsed_on_one_gpu():

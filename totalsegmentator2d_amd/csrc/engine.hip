@@ -171,6 +171,7 @@ struct ts2d_engine {
     bool use_h2 = true;           // "h2": 16-bit plain C -> C blocks on 16 x 32 tiles (0: conv3x3_h32); "h2_min": least channel count
     int h2_min = 64;
     bool use_uh2 = true;          // "uh2": 16-bit composed block on 16 x 32 tiles (0: conv3x3_upc_h)
+    bool use_sbk = true;          // "sbk": small batches - split-K (and the two-kernel decoder entry) where the preferred kernel would leave most CUs idle (fill_ksplit)
     bool use_first_split = true;  // "first_split": the first block's contraction as one fp16 hi / lo split product (kernels_first.h SPLIT; 0: exact fp32 MFMA)
     bool use_up0 = true;          // "up0": dedicated persistent kernel of the level-0 composed block (0: conv3x3_upc<32>)
     int u0seg = 0;                // "u0seg": tiles per workgroup segment of conv3x3_up0 (0: chosen from the grid; tests force segments that end inside an image)
@@ -195,6 +196,7 @@ struct ts2d_engine {
     bool keep_activations = false;                    // ts2d_engine_set_keep_activations: one buffer per tensor (debug access, full diagnosis)
     float* d_part = nullptr;
     float* d_partial = nullptr;   // split-K partial outputs
+    float* d_up = nullptr;        // scratch for ONE upsampled tensor (small batches: a decoder entry that the reserved batch's plan composes runs as two kernels)
     float* d_in_stage = nullptr; float* d_logit_stage = nullptr; uint32_t* d_mask_stage = nullptr;
     hipStream_t stream = nullptr;
     bool profiling = false;
@@ -982,6 +984,22 @@ int choose_ksplit(const Op& op, const TileGeom& g) {
     return S;
 }
 
+// Small batches (round 6).  TS2D.predict runs tiles x mirrors = 8 slices per sub-model and the reference one (B = 1 per network() call,
+// ts2d/core/inference/prediction_worker.py:209): at the <= 32 x 32 levels the persistent / composed kernels then launch 4 ... 64 workgroups on 256 CUs, each
+// walking 16 ... 64 channel chunks in series (B = 1: enc5.c0 0.21 ms for 0.6 GMAC).  When the one-image kernel of an op would launch fewer workgroups than
+// the chip has CUs, K is split until it does (>= 4 chunks per slice; deterministic two-phase reduction, splitk_reduce_stats), and a composed decoder entry
+// runs as transposed conv + conv (the composed kernels have no split-K form).  The factor depends on B: a slice is bit-identical alone or in a batch only
+// while both batches take the same path (tests compare across regimes at 2e-6); the same B always gives the same bits.
+// Measured (profiles/r06_small_batch.txt, wall time of a forward, split mode): B = 1 2.51 -> 1.90 ms, B = 2 2.77 -> 2.15, B = 4 3.27 -> 2.82, B = 8 4.32 -> 3.98;
+// filling to TWO workgroups per CU instead of one: equal (the reduction pass of each further split op costs what its conv gains).
+constexpr size_t kSbkElems = (size_t)2 * 256 * 256 * 64;      // S x B x HW x Cout of any op this rule splits (n_wgs S < 2 x 256 CUs, <= 256 pixels x 64 columns each)
+int fill_ksplit(const ts2d_engine* e, long long n_wgs, int nchunks) {
+    if (!e->use_sbk || e->num_cus > 256) return 1;            // (the bound above assumes <= 256 CUs)
+    int S = 1;
+    while (S < 8 && n_wgs * S < e->num_cus && nchunks / (S * 2) >= 4) S *= 2;
+    return S;
+}
+
 // ------------------------------------------------------------------------------------------------------------------ dispatch
 // ONE function decides which kernel serves an op for (precision, options, B, H, W).  The activation plan (which tensors exist), the
 // workspace sizing and the run (what is launched) all ask it, so they cannot disagree (the eligibility tests
@@ -1012,6 +1030,13 @@ Kern composed_kernel(const ts2d_engine* e, const Op& op, int B, int H, int W) {
                                                                                            //  before the workspace - and the pointers - exist)
     if (f16 && (op.cin_skip % 32 || !srcs_normed)) return K_NONE;       // (the 16-bit kernels walk the skip channels in chunks of 32 and normalise both sources)
     const int Ht = H >> op.ly, Wt = W >> op.lx;
+    if (!(op.up0_ok && e->use_up0)) {
+        // small batch: the two-kernel path when its conv would run with split-K (fill_ksplit) and the upsampled tensor fits the scratch region
+        const TileGeom g1 = tile_geom(B, Ht, Wt, 1, 1, 9);
+        const int chunk = f16 ? 32 : 16, bn1 = op.cout % 64 == 0 ? 64 : 32;
+        const bool two_ok = up.split_ok && (f16 ? op.h32_ok : op.split_ok) && g1.NIMG == 1 && (size_t)B * Ht * Wt * up.cout <= kSbkElems / 2;
+        if (two_ok && fill_ksplit(e, (long long)g1.n_mtiles * (op.cout / bn1), ct_total(op) / chunk) > 1) return K_NONE;
+    }
     if (Ht % 8 || Wt % 32) {                                            // no complete 8 x 32 tiles: tiles that follow the extent (FLEX instances)
         bool ok = false;
         (void)tile_geom_upc(B, Ht, Wt, ok);
@@ -1022,6 +1047,7 @@ Kern composed_kernel(const ts2d_engine* e, const Op& op, int B, int H, int W) {
     if (op.up0_ok && e->use_up0 && srcs_normed && fits32((size_t)Ht * Wt * 32 * 4)) return K_UP0;
     if (!fits32((size_t)Ht * Wt * std::max(op.cout, op.cin_skip) * 4) || !fits32((size_t)(Ht / 2) * (Wt / 2) * up.cin * 4)) return K_NONE;
     const int bn = op.cout % 64 == 0 ? 64 : 32;
+
     if (f16) return (e->use_uh2 && bn == 64 && Ht % 16 == 0) ? K_UPC_H2 : K_UPC_H;
     const bool upq = e->use_upq && bn == 64 && up.cin >= e->upq_min && Ht % 16 == 0 && srcs_normed && up.cin <= 512 && op.cin_skip <= 512;
     return upq ? K_UPQ : K_UPC;           // (Cb = 128: conv3x3_upq no faster than conv3x3_upc, measured)
@@ -1085,21 +1111,28 @@ Choice choose(const ts2d_engine* e, size_t oi, int B, int H, int W) {
     }
     const bool img32 = fits32((size_t)Hin * Win * std::max(op.cin, op.cin_skip) * 4) && fits32((size_t)Ht * Wt * op.cout * 4);
     if (op.stride == 2) {
-        if (op.s2v2_ok && e->use_s2v2 && e->use_one && Ht % 8 == 0 && Wt % 32 == 0 && img32 && magic_ok(tile_fixed(B, Ht, Wt, 8, 32, 2, 2))) {
+        // small batch: the one-image kernel with split-K where it leaves most CUs idle (fill_ksplit); else the 512-thread kernel
+        int s2k = 1;
+        {
+            const TileGeom g1 = tile_geom(B, Ht, Wt, 2, 2, 9);
+            const int P1 = g1.PH * g1.PW * g1.NIMG;
+            if (e->use_one && g1.NIMG == 1 && P1 <= 5 * kBlock && img32) s2k = fill_ksplit(e, (long long)g1.n_mtiles * (op.cout / c.bn), op.cin / 8);
+        }
+        if (s2k == 1 && op.s2v2_ok && e->use_s2v2 && e->use_one && Ht % 8 == 0 && Wt % 32 == 0 && img32 && magic_ok(tile_fixed(B, Ht, Wt, 8, 32, 2, 2))) {
             // stride-2 block on complete 8 x 32 output tiles: one 512-thread workgroup per CU, up to 128 output columns
             c.k = K_S2_V2; c.bn = op.bn2; c.fused_stats = true;
             c.g = tile_fixed(B, Ht, Wt, 8, 32, 2, 2);
             return c;
         }
-        if (op.s2v2_ok && e->use_s2v2 && e->use_one && e->use_flex2 && img32 && (f16 || e->use_flex2 > 1)) {
+        if (s2k == 1 && op.s2v2_ok && e->use_s2v2 && e->use_one && e->use_flex2 && img32 && (f16 || e->use_flex2 > 1)) {
             // ... on the tile that divides the level (FLEX instance)
             bool ok = false;
             const TileGeom gs = tile_geom_s2v2(B, Ht, Wt, ok);
             if (ok && magic_ok(gs)) { c.k = K_S2_V2; c.bn = op.bn2; c.fused_stats = true; c.flex = true; c.g = gs; return c; }
         }
         c.g = tile_geom(B, Ht, Wt, 2, 2, 9);
-        c.ksplit = choose_ksplit(op, c.g);
-        c.fused_stats = c.g.NIMG == 1;
+        c.ksplit = std::max(choose_ksplit(op, c.g), s2k);
+        c.fused_stats = c.g.NIMG == 1 && c.ksplit == 1;
         const int P = c.g.PH * c.g.PW * c.g.NIMG;
         c.k = (e->use_one && c.g.NIMG == 1 && P <= 5 * kBlock && img32) ? K_S2_ONE : K_S2_GENERIC;
         return c;
@@ -1117,6 +1150,16 @@ Choice choose(const ts2d_engine* e, size_t oi, int B, int H, int W) {
     const int P = c.g.PH * c.g.PW * c.g.NIMG;
     const bool srcs_normed = src.normed && (op.skip < 0 || e->tensors[op.skip].normed);
     const bool tiles16 = Ht % 16 == 0 && Wt % 32 == 0 && c.g.NIMG == 1 && img32;          // complete 16 x 32 tiles
+    // small batch: split-K on the one-image kernels where they leave most CUs idle (fill_ksplit) - ahead of the 512-thread kernels, which have no split-K form
+    if (c.g.NIMG == 1 && img32 && op.cout % c.bn == 0) {
+        const bool can = f16 ? (op.h32_ok && e->use_h32 && P * 4 <= 6 * kBlock) : (e->use_one && P * 2 <= 3 * kBlock);
+        const int sk = can ? fill_ksplit(e, (long long)c.g.n_mtiles * (op.cout / c.bn), ct / (f16 ? 32 : 16)) : 1;
+        if (sk > 1) {
+            c.ksplit = sk; c.fused_stats = false;
+            c.k = f16 ? K_S1_H32 : K_S1_ONE;
+            return c;
+        }
+    }
     if (f16) {
         if (e->use_h2 && tiles16 && op.cout % 64 == 0 && op.skip < 0 && ct % 32 == 0 && src.normed && ct >= e->h2_min) {
             c.k = K_S1_H2; c.bn = 64;       // plain C -> C block on 16 x 32 tiles: the skip phase of conv3x3_upc_h2
@@ -1156,6 +1199,8 @@ size_t partial_floats_needed(const ts2d_engine* e, int B, int H, int W) {
         const Choice c = choose(e, i, B, H, W);
         if (c.ksplit > 1) mx = std::max(mx, (size_t)c.ksplit * B * (H >> op.ly) * (W >> op.lx) * op.cout);
     }
+    // a workspace sized for B also serves every smaller batch, whose ops may split K further (fill_ksplit): the bound of that rule
+    if (e->use_sbk) mx = std::max(mx, kSbkElems);
     return mx;
 }
 
@@ -1166,6 +1211,7 @@ size_t part_floats_needed(const ts2d_engine* e, int B, int H, int W) {
         if (op.type != OP_CONV) continue;
         const Choice c = choose(e, i, B, H, W);
         if (c.fused_stats) mx = std::max(mx, (size_t)B * c.g.tiles_x * c.g.tiles_y * c.ppt * op.cout * 4);      // (S, Q, K, n) per (tile, channel)
+        if (e->use_sbk) mx = std::max(mx, kSbkElems / 256 * 4);      // small-batch split-K (any smaller batch in this workspace): a partial per 256 pixels and channel
     }
     return mx;
 }
@@ -1243,7 +1289,7 @@ ActPlan plan_activations(const ts2d_engine* e, int B, int H, int W, bool keep) {
 }
 
 // Layout of the activation workspace for (B, H, W) under the engine's current precision mode, options and keep flag.
-struct WsLayout { ActPlan plan; std::vector<size_t> o_sc, o_sh; size_t o_part = 0, o_pk = 0, bytes = 0; };
+struct WsLayout { ActPlan plan; std::vector<size_t> o_sc, o_sh; size_t o_part = 0, o_pk = 0, o_up = 0, bytes = 0; };
 
 WsLayout workspace_layout(const ts2d_engine* e, int B, int H, int W) {
     WsLayout L;
@@ -1260,6 +1306,8 @@ WsLayout workspace_layout(const ts2d_engine* e, int B, int H, int W) {
     }
     L.o_part = off; off = align_up(off + part_floats_needed(e, B, H, W) * sizeof(float) + 256, 256);
     L.o_pk = off; off = align_up(off + partial_floats_needed(e, B, H, W) * sizeof(float) + 256, 256);   // split-K partials
+    // one upsampled tensor of a small batch's two-kernel decoder entry (composed_kernel): the plan above is the reserved batch's, where that entry is composed
+    L.o_up = off; if (e->use_sbk) off = align_up(off + kSbkElems / 2 * sizeof(float) + 256, 256);
     L.bytes = off;
     return L;
 }
@@ -1292,6 +1340,7 @@ int ensure_workspace(ts2d_engine* e, int B, int H, int W) {
     }
     e->d_part = reinterpret_cast<float*>(e->d_ws + L.o_part);
     e->d_partial = reinterpret_cast<float*>(e->d_ws + L.o_pk);
+    e->d_up = e->use_sbk ? reinterpret_cast<float*>(e->d_ws + L.o_up) : nullptr;
     return TS2D_OK;
 }
 
@@ -1417,6 +1466,17 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
     }
     const float* wts = e->d_weights;
     const std::vector<Choice>& plan = planned(e, B, H, W);
+    // a transposed conv that runs on its own although the workspace's plan (made for the reserved batch) composed it away: its output goes to the
+    // scratch region (small batches, composed_kernel; one such tensor is alive at a time - it is read by the very next op only)
+    for (size_t oi = 0; oi < e->ops.size(); ++oi) {
+        const Op& op = e->ops[oi];
+        if (op.type != OP_CONVT || plan[oi].k == K_FUSED_AWAY) continue;
+        Tensor& t = e->tensors[op.dst];
+        if (t.data != nullptr && t.data != e->d_up) continue;
+        if (!e->d_up || (size_t)B * (H >> t.ly) * (W >> t.lx) * t.C > kSbkElems / 2)
+            return fail(TS2D_ERR_STATE, "internal: op %s has no output buffer in the workspace plan", op.name.c_str());
+        t.data = e->d_up; t.resident = false;
+    }
     for (size_t oi = 0; oi < e->ops.size(); ++oi) {
         const Op& op = e->ops[oi];
         const Tensor& src = e->tensors[op.src];
@@ -1764,7 +1824,21 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
                 const int HW = Ht * Wt;
                 if (c.ksplit > 1) {
                     TRY(prof_begin(e, op.name + ".stats", st)); prof_kernel(e, "finalize_stats");
-                    if (f16) hipLaunchKernelGGL(splitk_reduce_stats<_Float16>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, c.ksplit, ca.kslice_stride,
+                    if (HW == 256) {            // one block of 32 pixel lanes per (image, 32 channels): output + scale / shift in one launch
+                        if (f16) hipLaunchKernelGGL((splitk_reduce_stats<_Float16, 32>), dim3(B, op.cout / 32), dim3(1024), 0, st, e->d_partial, c.ksplit, ca.kslice_stride,
+                                                    wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, reinterpret_cast<_Float16*>(dst.data), dst.scale, dst.shift);
+                        else hipLaunchKernelGGL((splitk_reduce_stats<float, 32>), dim3(B, op.cout / 32), dim3(1024), 0, st, e->d_partial, c.ksplit, ca.kslice_stride,
+                                                wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.data, dst.scale, dst.shift);
+                    } else if (HW % 256 == 0 && HW > 256) {
+                        // images of >= 256 pixels (the small-batch rule): one block per 256 pixels writes the output and a shifted partial, finalize_stats
+                        // combines them - the one-block-per-image kernel below would walk the image 8 pixels per memory round trip
+                        const int nblk = HW / 256;
+                        if (f16) hipLaunchKernelGGL(splitk_reduce_part<_Float16>, dim3(nblk, op.cout / 32, B), dim3(256), 0, st, e->d_partial, c.ksplit, ca.kslice_stride,
+                                                    wts + op.dev_b, op.cout, HW, reinterpret_cast<_Float16*>(dst.data), e->d_part);
+                        else hipLaunchKernelGGL(splitk_reduce_part<float>, dim3(nblk, op.cout / 32, B), dim3(256), 0, st, e->d_partial, c.ksplit, ca.kslice_stride,
+                                                wts + op.dev_b, op.cout, HW, dst.data, e->d_part);
+                        launch_finalize(B, op.cout, st, e->d_part, nblk, op.cout, B, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.scale, dst.shift);
+                    } else if (f16) hipLaunchKernelGGL(splitk_reduce_stats<_Float16>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, c.ksplit, ca.kslice_stride,
                                                 wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, reinterpret_cast<_Float16*>(dst.data), dst.scale, dst.shift);
                     else hipLaunchKernelGGL(splitk_reduce_stats<float>, dim3(B, op.cout / 32), dim3(256), 0, st, e->d_partial, c.ksplit, ca.kslice_stride,
                                             wts + op.dev_b, op.cout, HW, wts + op.dev_g, wts + op.dev_be, a.norm_eps, dst.data, dst.scale, dst.shift);
@@ -1861,7 +1935,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
     struct B { const char* n; bool* p; };
     struct I { const char* n; int* p; int lo, hi; };
     const B bools[] = {{"h32", &e->use_h32}, {"one", &e->use_one}, {"s2v2", &e->use_s2v2}, {"q", &e->use_q}, {"h2", &e->use_h2},  {"uh2", &e->use_uh2},
-                       {"first_split", &e->use_first_split}, {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}, {"flex", &e->use_flex}};
+                       {"first_split", &e->use_first_split}, {"sbk", &e->use_sbk}, {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}, {"flex", &e->use_flex}};
     const I ints[] = {{"upq_min", &e->upq_min, 0, 1 << 20}, {"h2_min", &e->h2_min, 0, 1 << 20}, {"u0seg", &e->u0seg, 0, 1 << 20}, {"flex2", &e->use_flex2, 0, 2}};
     bool found = false;
     for (const B& b : bools) if (!strcmp(name, b.n)) { *b.p = value != 0; found = true; }
@@ -1869,7 +1943,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
         if (value < i.lo || value > i.hi) return fail(TS2D_ERR_INVALID, "option %s = %d out of range [%d, %d]", name, value, i.lo, i.hi);
         *i.p = value; found = true;
     }
-    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0 flex flex2 first_split)", name);
+    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0 flex flex2 first_split sbk)", name);
     e->ws_precision = -1;         // which ops compose (and with it the activation plan) depends on the options: re-plan at the next reserve / forward
     ++e->opt_gen;
     return TS2D_OK;

@@ -446,17 +446,19 @@ __global__ __launch_bounds__(256) void stats_direct(const ST* __restrict__ x, in
 
 // (c) split-K epilogue for the tiny bottleneck layers: fixed-order sum of the S partial outputs + bias -> raw output,
 // and the InstanceNorm scale/shift of that output in the same pass.  Grid (B, C/32), 256 threads = 8 pixel lanes x 32 ch.
-template <typename ST>
-__global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restrict__ partial, int S, long long slice_stride,
+template <typename ST, int PL = 8>
+__global__ __launch_bounds__(32 * PL) void splitk_reduce_stats(const float* __restrict__ partial, int S, long long slice_stride,
                                                           const float* __restrict__ bias, int C, int HW,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, ST* __restrict__ dst, float* __restrict__ scale,
                                                           float* __restrict__ shift) {
     const int n = blockIdx.x, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, pl = threadIdx.x >> 5;
-    __shared__ double rs[8][32], rq[8][32];
+    __shared__ double rs[PL][32], rq[PL][32];
     const float b = bias[c];
     double s = 0.0, q = 0.0;
-    for (int p = pl; p < HW; p += 8) {
+    // (PL = 32, round 6: images of 256 ... 1024 pixels under the small-batch split-K - four pixels' partials in flight per thread)
+#pragma unroll PL == 32 ? 4 : 1
+    for (int p = pl; p < HW; p += PL) {
         const size_t o = ((size_t)n * HW + p) * C + c;
         float v = 0.f;
         for (int k0 = 0; k0 < S; k0 += 8) {             // the partials of 8 splits requested together, added in the fixed order k = 0, 1, ...
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restri
     rs[pl][cl] = s; rq[pl][cl] = q;
     __syncthreads();
     if (pl == 0) {
-        for (int k = 1; k < 8; ++k) { s += rs[k][cl]; q += rq[k][cl]; }
+        for (int k = 1; k < PL; ++k) { s += rs[k][cl]; q += rq[k][cl]; }
         const double mean = s / HW;
         double var = q / HW - mean * mean;
         var = var > 0.0 ? var : 0.0;
@@ -482,6 +484,47 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats(const float* __restri
         const double g = gamma[c];
         scale[(size_t)n * C + c] = (float)(g * rstd);
         shift[(size_t)n * C + c] = (float)((double)beta[c] - mean * g * rstd);
+    }
+}
+
+// (d) split-K epilogue for images of >= 256 pixels (round 6: the small-batch split-K of the 16 x 16 ... 128 x 128 levels).  Grid (HW / 256, C / 32, B),
+// 256 threads = 8 pixel lanes x 32 channels: fixed-order sum of the S partial outputs + bias -> raw output, and ONE shifted partial (S, Q, K, n = 256) per
+// block and channel in the layout of the conv epilogues' tile partials ([n][block][C]); finalize_stats_t turns them into scale / shift.  The pivot is the
+// value of the block's first pixel; the value of a pixel and the partial depend on the slice's own data and the split factor only.
+template <typename ST>
+__global__ __launch_bounds__(256) void splitk_reduce_part(const float* __restrict__ partial, int S, long long slice_stride,
+                                                         const float* __restrict__ bias, int C, int HW, ST* __restrict__ dst, float* __restrict__ part) {
+    const int blk = blockIdx.x, n = blockIdx.z, cl = threadIdx.x & 31, c = blockIdx.y * 32 + cl, pl = threadIdx.x >> 5;
+    __shared__ float rs[8][32], rq[8][32];
+    const float b = bias[c];
+    auto value = [&](int p) -> float {
+        const size_t o = ((size_t)n * HW + p) * C + c;
+        float v = 0.f;
+        for (int k0 = 0; k0 < S; k0 += 8) {             // the partials of 8 splits requested together, added in the fixed order k = 0, 1, ...
+            float pk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = partial[(size_t)(k0 + j < S ? k0 + j : k0) * slice_stride + o];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (k0 + j < S) v += pk[j];
+        }
+        return v + b;
+    };
+    const int p0 = blk * 256;
+    const float kv = (float)(ST)value(p0);               // (every pixel lane recomputes the pivot: L1 hits, no barrier)
+    float s = 0.f, q = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+        const int p = p0 + pl + 8 * i;
+        const float v = value(p);
+        dst[((size_t)n * HW + p) * C + c] = (ST)v;
+        const float d = (float)(ST)v - kv;
+        s += d; q = __builtin_fmaf(d, d, q);
+    }
+    rs[pl][cl] = s; rq[pl][cl] = q;
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < 8; ++k) { s += rs[k][cl]; q += rq[k][cl]; }
+        *reinterpret_cast<f32x4*>(part + (((size_t)n * (HW / 256) + blk) * C + c) * 4) = f32x4{s, q, kv, 256.f};
     }
 }
 

@@ -38,6 +38,9 @@ def _is_torch(x) -> bool:
 
 
 class Engine:
+    default_options: Dict[str, int] = {}     # dispatch options every new handle starts with (empty in the product; test modules that address
+                                             # the large-batch kernels at small B set {'sbk': 0})
+
     def __init__(self, arch: UNetArch, blob: Optional[np.ndarray], device: int = 0, options: Optional[Dict[str, int]] = None):
         """blob: fp32 weight blob (:func:`weights.pack_blob`) or None for a replica to be filled by broadcast.
         options: kernel-dispatch options (:meth:`set_option`), e.g. ``{'upc': 0}`` - tests and A/B scripts."""
@@ -59,7 +62,7 @@ class Engine:
         else:
             _lib.check(self.lib.ts2d_engine_create(ctypes.byref(d), None, 0, self.device, ctypes.byref(self._h)),
                        'ts2d_engine_create')
-        for k, v in (options or {}).items():
+        for k, v in {**Engine.default_options, **(options or {})}.items():
             self.set_option(k, v)
 
     # ------------------------------------------------------------------ lifetime
