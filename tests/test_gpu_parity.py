@@ -486,6 +486,31 @@ def test_f16_per_layer_oracle_on_the_256_and_512_channel_kernels_of_the_canonica
             assert got.shape == want.shape and _f16_layer_ok(n, got, want), (n, float(np.abs(got - want).max()), float(np.sqrt(np.mean((got - want) ** 2))))
 
 
+@pytest.mark.parametrize('k32', [1, 0])
+def test_f16_per_layer_oracle_on_the_stride_2_kernels_of_the_canonical_net(k32):
+    """The 512-thread stride-2 kernel of the 16-bit mode on 32-channel chunks (round 6, "s2k32": the second part of its LDS images holds
+    channels 16-31 of the chunk - half the items and barriers per tile) and on 16-channel chunks: enc1.c0 (resident weights, 64 columns),
+    enc2 ... enc4.c0 (weights by DMA, 128 columns, 2 ... 8 chunks of 32) and enc5.c0 (the extent-following 16 x 16 tile), each block from
+    the engine's own input against ONE block of the 16-bit oracle."""
+    from oracle import torch_oracle as O
+    arch = UNetArch.canonical()
+    sd, blob = blob_for(arch, 1)
+    x = cases.make_input(arch, 2, 512, 512, 2)
+    prog = {o['name']: o for o in arch.program()}
+    with Engine(arch, blob, options={'s2k32': k32}) as e:
+        e.set_precision('f16')
+        e.set_profiling(True)
+        lg, _ = e.forward(x, logits=True)
+        kern = e.op_kernels()
+        for n in ('enc1.c0', 'enc2.c0', 'enc3.c0', 'enc4.c0', 'enc5.c0'):
+            assert kern[n].startswith('conv3x3s2_v2<') and kern[n].endswith(',k32>') == bool(k32), (n, kern[n])
+            got = e.debug_tensor(n)
+            want = O.layer_forward(arch, sd, n, e.debug_tensor(prog[n]['src']), emulate='f16', storage_view=True).numpy()
+            assert got.shape == want.shape and _f16_layer_ok(n, got, want), (n, float(np.abs(got - want).max()), float(np.sqrt(np.mean((got - want) ** 2))))
+        d = lg[:1] - O.unet_forward(arch, sd, x[:1], emulate='f16').numpy()
+        assert np.abs(d).max() <= F16E_MAX and np.sqrt((d ** 2).mean()) <= F16E_RMS
+
+
 def test_config3_config5_in_f16():
     """Config 3 (a 26-head sub-model, 512x512) and config 5 (tsxr: 1-channel 1024x1024, 9 stages) in the 16-bit mode, against the
     16-bit oracle (tight) and the fp32 oracle (what the mode costs)."""

@@ -171,6 +171,7 @@ struct ts2d_engine {
     bool use_h2 = true;           // "h2": 16-bit plain C -> C blocks on 16 x 32 tiles (0: conv3x3_h32); "h2_min": least channel count
     int h2_min = 64;
     bool use_uh2 = true;          // "uh2": 16-bit composed block on 16 x 32 tiles (0: conv3x3_upc_h)
+    bool use_s2k32 = true;        // "s2k32": 16-bit mode - the 512-thread stride-2 kernel on 32-channel chunks (0: 16-channel chunks)
     bool use_sbk = true;          // "sbk": small batches - split-K (and the two-kernel decoder entry) where the preferred kernel would leave most CUs idle (fill_ksplit)
     bool use_first_split = true;  // "first_split": the first block's contraction as one fp16 hi / lo split product (kernels_first.h SPLIT; 0: exact fp32 MFMA)
     bool use_up0 = true;          // "up0": dedicated persistent kernel of the level-0 composed block (0: conv3x3_upc<32>)
@@ -1726,21 +1727,23 @@ int run_forward_impl(ts2d_engine* e, const float* d_in, int B, int H, int W, flo
             switch (c.k) {
             case K_S2_V2: {
                 ca.wph = wts + op.dev_w2; ca.oscale = wts + op.dev_ws;
-                const int npp = f16 ? 1 : 2;
+                // 16-bit mode: chunks of 32 channels (the second part of the LDS images = channels 16-31 instead of the split mode's lo parts; kernels_s2v2.h K32)
+                const bool k32 = f16 && e->use_s2k32 && op.cin % 32 == 0;
+                const int npp = (f16 && !k32) ? 1 : 2, nch = op.cin / (k32 ? 32 : 16);
                 // persistent: one workgroup per CU walks its tiles; every chunk's weights resident in LDS when they fit beside the patch
                 const size_t wchunk = (size_t)9 * npp * 2 * op.bn2 * 16;
-                const bool resw = (size_t)npp * 2 * kS2Plane + (size_t)(op.cin / 16) * wchunk <= (size_t)160 * 1024;
+                const bool resw = (size_t)npp * 2 * kS2Plane + (size_t)nch * wchunk <= (size_t)160 * 1024;
                 const int grid2 = std::min(grid, 8 * ca.n_ctiles * std::max(1, e->num_cus / (8 * ca.n_ctiles)));
-                const size_t smem2 = (size_t)npp * 2 * kS2Plane + (resw ? (size_t)(op.cin / 16) : 1) * wchunk;
-                prof_kernel(e, op.bn2 == 128 ? "conv3x3s2_v2<128>" : "conv3x3s2_v2<64>");
-#define TS2D_S2V2_INST(BN_, ST_, NP_, RW_, FX_) do { static std::atomic<uint64_t> done_{0}; \
-                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, RW_, FX_>), done_)); \
-                    hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, RW_, FX_>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } while (0)
-#define TS2D_S2V2_LAUNCH(BN_, ST_, NP_) do { \
-                    if (resw) { if (c.flex) TS2D_S2V2_INST(BN_, ST_, NP_, true, true); else TS2D_S2V2_INST(BN_, ST_, NP_, true, false); } \
-                    else { if (c.flex) TS2D_S2V2_INST(BN_, ST_, NP_, false, true); else TS2D_S2V2_INST(BN_, ST_, NP_, false, false); } } while (0)
-                if (op.bn2 == 128) { if (f16) TS2D_S2V2_LAUNCH(128, _Float16, 1); else TS2D_S2V2_LAUNCH(128, float, 3); }
-                else { if (f16) TS2D_S2V2_LAUNCH(64, _Float16, 1); else TS2D_S2V2_LAUNCH(64, float, 3); }
+                const size_t smem2 = (size_t)npp * 2 * kS2Plane + (resw ? (size_t)nch : 1) * wchunk;
+                prof_kernel(e, op.bn2 == 128 ? (k32 ? "conv3x3s2_v2<128,k32>" : "conv3x3s2_v2<128>") : (k32 ? "conv3x3s2_v2<64,k32>" : "conv3x3s2_v2<64>"));
+#define TS2D_S2V2_INST(BN_, ST_, NP_, RW_, FX_, K_) do { static std::atomic<uint64_t> done_{0}; \
+                    HIP_TRY(allow_max_lds(reinterpret_cast<const void*>(conv3x3s2_v2<BN_, ST_, NP_, RW_, FX_, K_>), done_)); \
+                    hipLaunchKernelGGL((conv3x3s2_v2<BN_, ST_, NP_, RW_, FX_, K_>), dim3(grid2), dim3(kS2Threads), smem2, st, ca); } while (0)
+#define TS2D_S2V2_LAUNCH(BN_, ST_, NP_, K_) do { \
+                    if (resw) { if (c.flex) TS2D_S2V2_INST(BN_, ST_, NP_, true, true, K_); else TS2D_S2V2_INST(BN_, ST_, NP_, true, false, K_); } \
+                    else { if (c.flex) TS2D_S2V2_INST(BN_, ST_, NP_, false, true, K_); else TS2D_S2V2_INST(BN_, ST_, NP_, false, false, K_); } } while (0)
+                if (op.bn2 == 128) { if (k32) TS2D_S2V2_LAUNCH(128, _Float16, 1, true); else if (f16) TS2D_S2V2_LAUNCH(128, _Float16, 1, false); else TS2D_S2V2_LAUNCH(128, float, 3, false); }
+                else { if (k32) TS2D_S2V2_LAUNCH(64, _Float16, 1, true); else if (f16) TS2D_S2V2_LAUNCH(64, _Float16, 1, false); else TS2D_S2V2_LAUNCH(64, float, 3, false); }
 #undef TS2D_S2V2_LAUNCH
 #undef TS2D_S2V2_INST
                 le = hipGetLastError();
@@ -1935,7 +1938,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
     struct B { const char* n; bool* p; };
     struct I { const char* n; int* p; int lo, hi; };
     const B bools[] = {{"h32", &e->use_h32}, {"one", &e->use_one}, {"s2v2", &e->use_s2v2}, {"q", &e->use_q}, {"h2", &e->use_h2},  {"uh2", &e->use_uh2},
-                       {"first_split", &e->use_first_split}, {"sbk", &e->use_sbk}, {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}, {"flex", &e->use_flex}};
+                       {"first_split", &e->use_first_split}, {"sbk", &e->use_sbk}, {"s2k32", &e->use_s2k32}, {"up0", &e->use_up0}, {"upq", &e->use_upq}, {"upc", &e->use_upc}, {"res", &e->use_res}, {"fuse0", &e->use_fuse0}, {"flex", &e->use_flex}};
     const I ints[] = {{"upq_min", &e->upq_min, 0, 1 << 20}, {"h2_min", &e->h2_min, 0, 1 << 20}, {"u0seg", &e->u0seg, 0, 1 << 20}, {"flex2", &e->use_flex2, 0, 2}};
     bool found = false;
     for (const B& b : bools) if (!strcmp(name, b.n)) { *b.p = value != 0; found = true; }
@@ -1943,7 +1946,7 @@ int ts2d_engine_set_option(ts2d_engine* e, const char* name, int value) {
         if (value < i.lo || value > i.hi) return fail(TS2D_ERR_INVALID, "option %s = %d out of range [%d, %d]", name, value, i.lo, i.hi);
         *i.p = value; found = true;
     }
-    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0 flex flex2 first_split sbk)", name);
+    if (!found) return fail(TS2D_ERR_INVALID, "unknown option '%s' (h32 one s2v2 q h2 h2_min uh2 up0 u0seg upq upq_min upc res fuse0 flex flex2 first_split sbk s2k32)", name);
     e->ws_precision = -1;         // which ops compose (and with it the activation plan) depends on the options: re-plan at the next reserve / forward
     ++e->opt_gen;
     return TS2D_OK;

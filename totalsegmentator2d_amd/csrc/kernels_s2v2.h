@@ -53,16 +53,26 @@ static_assert(kS2Plane % 128 == 64, "plane stride of conv3x3s2_v2");
 // the 16 x 16 level of the canonical net).  Tiles divide the level exactly, so - as with the fixed tile - a patch leaves the image at the top
 // and the left only.  Row m of the tile's GEMM is pixel (m / TW, m % TW): lane bases by division (once), tap offsets in registers, rows
 // past TH * TW read a dummy slot and are masked in the epilogue (which addresses per run of 4 pixels).
-template <int BN, typename ST, int NP, bool RESW, bool FLEX = false>
+// K32 (round 6, 16-bit mode): chunks of 32 channels.  With fp16 storage a pixel's 32-channel slice is as many bytes as the split mode's hi + lo of 16, so
+// the second PART of every LDS image (the split mode's lo planes / lo weight blocks) holds channels 16-31 of the chunk instead: half the items, barriers
+// and staging phases per tile for the same MFMAs (two per tap and block pair: part 0 x part 0 + part 1 x part 1), four lanes per pixel in the loads like
+// the fp32 path, no per-chunk accumulator (one product, fp32 accumulation: the 16-bit contract).  The 16-channel form at one product spent two thirds of an
+// item outside its taps (profiles/r04_s2v2_stamps.txt: conversion 4.7 k + barriers 2.1 k + accumulate 3.9 k cycles beside 5.2 k of taps, single-buffered).
+template <int BN, typename ST, int NP, bool RESW, bool FLEX = false, bool K32 = false>
 __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) {
+    static_assert(!K32 || (NP == 1 && sizeof(ST) == 2), "32-channel chunks: fp16 storage, one product");
     constexpr int NPP = NP == 3 ? 2 : 1;                   // fp16 parts per value
+    constexpr int PARTS = K32 ? 2 : NPP;                   // LDS planes / weight blocks per (tap, k half): hi, lo - or channels 0-15, 16-31 of a K32 chunk
+    constexpr int CK = K32 ? 32 : 16;                      // channels per chunk
     constexpr int NTW = BN / 64;                           // 32-column MFMA tiles per wave (a wave owns BN / 2 columns)
-    constexpr int WTAP = NPP * 2 * BN * 16, WB = 9 * WTAP; // weight bytes per tap / per chunk
+    constexpr int WTAP = PARTS * 2 * BN * 16, WB = 9 * WTAP; // weight bytes per tap / per chunk
     constexpr bool F32 = sizeof(ST) == 4;
-    // staging unit = 16 bytes of a pixel's 16-channel slice.  fp32 storage: a quarter (4 channels), four lanes per pixel, 9 units per
-    // thread (9 x 128 slots >= 1122); fp16 storage: a half (8 channels), two lanes per pixel, 5 units per thread (5 x 256 slots)
-    constexpr int MAXU = F32 ? 9 : 5;
-    constexpr int USTEP = F32 ? 128 : 256;                 // slots covered by one unit index of the whole workgroup
+    constexpr bool Q4 = F32 || K32;                        // four lanes per pixel (a pixel's slice of the chunk is 64 bytes)
+    // staging unit = 16 bytes of a pixel's slice of the chunk.  fp32 storage: a quarter (4 channels), four lanes per pixel, 9 units per
+    // thread (9 x 128 slots >= 1122); fp16 storage: a half (8 channels), two lanes per pixel, 5 units per thread (5 x 256 slots) - K32: a quarter
+    // (8 of 32 channels), four lanes per pixel
+    constexpr int MAXU = Q4 ? 9 : 5;
+    constexpr int USTEP = Q4 ? 128 : 256;                  // slots covered by one unit index of the whole workgroup
     constexpr int DEPTH = BN == 64 ? 2 : 1;                // items kept in flight in registers (BN = 64: enc1.c0 runs at the HBM rate; two items keep that pipe fed)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     const int mtile0 = qm0 * 8 + xcd, mstep = ((int)(gridDim.x >> 3) / a.n_ctiles) * 8;
     if (mtile0 >= a.n_mtiles) return;
     const int ntl = (a.n_mtiles - 1 - mtile0) / mstep + 1;
-    const int nchunks = a.C0 / 16;                         // the strided conv never reads a concat
+    const int nchunks = a.C0 / CK;                         // the strided conv never reads a concat
     const int tpi = a.tiles_x * a.tiles_y;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -85,14 +95,14 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     const int r = lane & 31, h = lane >> 5;
 
     unsigned char* sA = smem8;                             // [part][h][slot] x 16 B
-    unsigned char* sB = smem8 + NPP * 2 * kS2Plane;        // [chunk (RESW)][tap][part][h][column BN] x 16 B
+    unsigned char* sB = smem8 + PARTS * 2 * kS2Plane;      // [chunk (RESW)][tap][part][h][column BN] x 16 B
 
     // ---- staging plan (tile-independent).  Slot q = patch row q / 66, then the 33 even columns, then the 33 odd ones (the 66th slot of
     //      a row is unused).  fp32: unit it of thread tid = slot (tid >> 2) + 128 it, quarter sub = tid & 3 (channels 4 sub .. 4 sub + 3 of the
     //      chunk: plane h = sub >> 1, bytes 8 (sub & 1) .. of the slot); fp16: slot 32 (8 it + w) + (lane & 7) + 8 (lane >> 4), octet
     //      sub = (lane >> 3) & 1 (plane h = sub).
-    const int sub = F32 ? (tid & 3) : ((lane >> 3) & 1);
-    const int slot0 = F32 ? (tid >> 2) : (32 * w + (lane & 7) + 8 * (lane >> 4));
+    const int sub = Q4 ? (tid & 3) : ((lane >> 3) & 1);    // (K32: channels 8 sub .. 8 sub + 7 of the chunk = part sub >> 1, plane h = sub & 1: plane index = sub)
+    const int slot0 = Q4 ? (tid >> 2) : (32 * w + (lane & 7) + 8 * (lane >> 4));
     unsigned rel[MAXU];                                    // byte offset of the unit from the patch origin, 0x80000000 = no unit
     unsigned emask = 0;                                    // per unit: bit 0 = patch row 0, bit 1 = patch column 0 (the padding candidates)
     const int lw0 = F32 ? (sub >> 1) * kS2Plane + slot0 * 16 + (sub & 1) * 8 : sub * kS2Plane + slot0 * 16;      // LDS write address of unit 0; unit it: + 16 USTEP it
@@ -116,12 +126,19 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     if constexpr (RESW) {                                  // resident weights: chunks x 9 taps of this column tile, one linear copy each
         constexpr int WIT = (WB / 16 + kS2Threads - 1) / kS2Threads;
         for (int c = 0; c < nchunks; ++c) {
-            const uint4* wsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(a.wph) + ((size_t)c * a.n_ctiles + ctile) * (9 * 2 * 2 * BN * 16));
+            // (the weight image is the split mode's: [16-channel chunk][column tile][tap][hi, lo][h][column]; the 16-bit forms read the hi blocks - K32 those
+            //  of the chunks 2 c and 2 c + 1 as its two parts)
+            const uint4* wsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(a.wph) + ((size_t)(K32 ? 2 * c : c) * a.n_ctiles + ctile) * (9 * 2 * 2 * BN * 16));
+            constexpr int C16 = 9 * 4 * BN;                // uint4s of one 16-channel chunk's block
 #pragma unroll
             for (int k = 0; k < WIT; ++k) {
                 const int sl = tid + k * kS2Threads;
-                if (WB / 16 % kS2Threads == 0 || sl < WB / 16)
-                    *reinterpret_cast<uint4*>(sB + c * WB + sl * 16) = wsrc[NPP == 2 ? sl : (sl / (2 * BN)) * (4 * BN) + sl % (2 * BN)];
+                if (WB / 16 % kS2Threads == 0 || sl < WB / 16) {
+                    int src = sl;
+                    if constexpr (K32) src = ((sl / (2 * BN)) & 1) * (C16 * a.n_ctiles) + (sl / (4 * BN)) * (4 * BN) + sl % (2 * BN);
+                    else if constexpr (NPP == 1) src = (sl / (2 * BN)) * (4 * BN) + sl % (2 * BN);
+                    *reinterpret_cast<uint4*>(sB + c * WB + sl * 16) = wsrc[src];
+                }
             }
         }
     }
@@ -144,8 +161,8 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
     const bool normed = a.sc0 != nullptr;
     auto load_norm = [&](Stage& S, int nimg, int c) {      // scale / shift of this thread's channels (not normalised: loaded, not used)
         const int co = F32 ? 4 * sub : 8 * sub;
-        const float* ps = (normed ? a.sc0 : a.bias) + (normed ? (size_t)nimg * a.C0 + c * 16 + co : 0);
-        const float* pt = (normed ? a.sh0 : a.bias) + (normed ? (size_t)nimg * a.C0 + c * 16 + co : 0);
+        const float* ps = (normed ? a.sc0 : a.bias) + (normed ? (size_t)nimg * a.C0 + c * CK + co : 0);
+        const float* pt = (normed ? a.sh0 : a.bias) + (normed ? (size_t)nimg * a.C0 + c * CK + co : 0);
         S.nsa = *reinterpret_cast<const f32x4*>(ps); S.nta = *reinterpret_cast<const f32x4*>(pt);
         if constexpr (!F32) { S.nsb = *reinterpret_cast<const f32x4*>(ps + 4); S.ntb = *reinterpret_cast<const f32x4*>(pt + 4); }
     };
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         // units are padding (zeroed at conversion)
         q.org = FLEX ? (unsigned)((((2 * TH * tyi - 1) * a.Win + 2 * TW * txi - 1) * a.C0) * (int)sizeof(ST))
                      : (unsigned)((((16 * tyi - 1) * a.Win + 64 * txi - 1) * a.C0) * (int)sizeof(ST));
-        q.soff = t.c * 16 * (int)sizeof(ST);
+        q.soff = t.c * CK * (int)sizeof(ST);
         return q;
     };
     auto load_unit = [&](Stage& S, const Req& q, int it) {
@@ -197,7 +214,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
             fxb[mt] = h * kS2Plane + (m < TH * TW ? (2 * ty * PW2 + tx) * 16 : 0);
         }
     }
-    const int bbase = NPP * 2 * kS2Plane + h * BN * 16 + (wn * (BN / 2) + r) * 16;  // + chunk * WB (RESW) + tap * WTAP + part * 2 * BN * 16 + nt * 512
+    const int bbase = PARTS * 2 * kS2Plane + h * BN * 16 + (wn * (BN / 2) + r) * 16;  // + chunk * WB (RESW) + tap * WTAP + part * 2 * BN * 16 + nt * 512
     const _Float16 slope_h = (_Float16)a.slope;
     const unsigned slope2 = (unsigned)__builtin_bit_cast(unsigned short, slope_h) * 0x10001u;
     const f32x4 slope4 = f32x4{a.slope, a.slope, a.slope, a.slope};
@@ -230,17 +247,22 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
             asm volatile("" :: "v"(nsa), "v"(nta));
             if constexpr (!F32) asm volatile("" :: "v"(nsb), "v"(ntb));
             TS2D_STAMP_AT(a.prof, 2)
-            const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wph) + ((size_t)cur.c * a.n_ctiles + ctile) * (9 * 2 * 2 * BN * 16) + lane * 16;
+            const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wph) + ((size_t)(K32 ? 2 * cur.c : cur.c) * a.n_ctiles + ctile) * (9 * 2 * 2 * BN * 16) + lane * 16;
             constexpr int NPIECE = WB / 1024, RUN = 2 * BN * 16 / 1024;      // f16 mode: the hi parts only - runs of RUN pieces out of every 2 RUN
+            const size_t c16 = (size_t)a.n_ctiles * (9 * 2 * 2 * BN * 16);   // (K32) bytes from the block of chunk 2 c to that of chunk 2 c + 1
 #pragma unroll
             for (int j = 0; j < (NPIECE + 7) / 8; ++j) {
                 const int pc = w + 8 * j;
-                if (NPIECE % 8 == 0 || pc < NPIECE)
-                    __builtin_amdgcn_global_load_lds(wsrc + (NPP == 2 ? pc : (pc / RUN) * 2 * RUN + pc % RUN) * 1024, (lds_ptr)(sB + pc * 1024), 16, 0, 0);
+                if (NPIECE % 8 == 0 || pc < NPIECE) {
+                    size_t so;                             // piece pc of the LDS image [tap][part][RUN pieces] <- piece of the source image [tap][hi, lo][RUN]
+                    if constexpr (K32) so = (size_t)((pc / RUN) & 1) * c16 + (size_t)((pc / (2 * RUN)) * 2 * RUN + pc % RUN) * 1024;
+                    else so = (size_t)(NPP == 2 ? pc : (pc / RUN) * 2 * RUN + pc % RUN) * 1024;
+                    __builtin_amdgcn_global_load_lds(wsrc + so, (lds_ptr)(sB + pc * 1024), 16, 0, 0);
+                }
             }
         }
         // ---- patch: InstanceNorm + LeakyReLU on the fly, split into fp16 hi / lo; padding units store zeros
-        constexpr unsigned kRow0 = F32 ? 0x15555u : 0x155u, kCol0 = F32 ? 0x2AAAAu : 0x2AAu;
+        constexpr unsigned kRow0 = Q4 ? 0x15555u : 0x155u, kCol0 = Q4 ? 0x2AAAAu : 0x2AAu;
         const unsigned pad = (tyi == 0 ? kRow0 : 0u) | (txi == 0 ? kCol0 : 0u);      // (uniform) which emask bits mean "outside the image" here
         const bool border = pad != 0u;                     // (uniform) interior tiles skip the zero-selects
 #pragma unroll
@@ -277,26 +299,33 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         int nimg_pf;
         const Req rq = request(pf, nimg_pf);               // the item DEPTH ahead (possibly of another tile) into the registers just converted:
                                                            // its units are issued one per tap below
-        f32x16 acc_c[2][NTW];                              // fresh accumulator per chunk (accuracy)
+        f32x16 acc_c[K32 ? 1 : 2][K32 ? 1 : NTW];          // fresh accumulator per chunk (accuracy; K32: straight into the tile's)
         const unsigned char* pw = smem8 + bbase + (RESW ? cur.c * WB : 0);
         __builtin_amdgcn_s_setprio(1);
         // fragments of tap t+1 are read while the MFMAs of tap t run (two register sets, one scheduling region per tap: the plain
         // loop waited for every tap's reads before its MFMAs)
-        auto load_frags = [&](half8 (&fa)[2][NPP], half8 (&fb)[NTW][NPP], int tap) {
+        auto load_frags = [&](half8 (&fa)[2][PARTS], half8 (&fb)[NTW][PARTS], int tap) {
             const int dy = tap / 3, dx = tap - 3 * dy;
             const int toff = (dy * PW2 + (dx & 1) * HO + (dx >> 1)) * 16;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int p = 0; p < NPP; ++p)
+                for (int p = 0; p < PARTS; ++p)
                     fa[mt][p] = *reinterpret_cast<const half8*>(smem8 + (FLEX ? fxb[mt] : abase + mt * 2 * kS2PW * 16) + p * 2 * kS2Plane + toff);
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-                for (int p = 0; p < NPP; ++p) fb[nt][p] = *reinterpret_cast<const half8*>(pw + tap * WTAP + p * 2 * BN * 16 + nt * 512);
+                for (int p = 0; p < PARTS; ++p) fb[nt][p] = *reinterpret_cast<const half8*>(pw + tap * WTAP + p * 2 * BN * 16 + nt * 512);
         };
-        auto mma = [&](half8 (&fa)[2][NPP], half8 (&fb)[NTW][NPP], bool first) {
-            if constexpr (NP == 3) {
+        auto mma = [&](half8 (&fa)[2][PARTS], half8 (&fb)[NTW][PARTS], bool first) {
+            if constexpr (K32) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) acc_t[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][p], fb[nt][p], acc_t[mt][nt], 0, 0, 0);
+            } else if constexpr (NP == 3) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -317,7 +346,7 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
             }
         };
         {
-            half8 fa0[2][NPP], fb0[NTW][NPP], fa1[2][NPP], fb1[NTW][NPP];
+            half8 fa0[2][PARTS], fb0[NTW][PARTS], fa1[2][PARTS], fb1[NTW][PARTS];
             load_frags(fa0, fb0, 0);
             // one patch load of the next request per tap, behind the tap's MFMAs (units MAXU .. 8 do not exist in the 16-bit mode)
 #define TS2D_TAP2(T) { if constexpr ((T) + 1 < 9) { if constexpr ((T) & 1) load_frags(fa0, fb0, (T) + 1); else load_frags(fa1, fb1, (T) + 1); } \
@@ -331,10 +360,12 @@ __global__ __launch_bounds__(kS2Threads, 2) void conv3x3s2_v2(const ConvArgs a) 
         __builtin_amdgcn_s_setprio(0);
         if (younger) __builtin_amdgcn_s_setprio(1);
         TS2D_STAMP_AT(a.prof, 5)
+        if constexpr (!K32) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
+                for (int nt = 0; nt < NTW; ++nt) acc_t[mt][nt] += acc_c[mt][nt];
+        }
 
         if (cur.c == nchunks - 1) {                        // (uniform) the tile is complete
             // ---- epilogue: C/D map of the 32x32 MFMA: column = lane & 31 (output channel), row = (i & 3) + 8 (i >> 2) + 4 h (pixel ox)
