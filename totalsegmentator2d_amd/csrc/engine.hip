@@ -1013,6 +1013,8 @@ inline bool magic_ok(const TileGeom& g) { return (unsigned long long)g.n_mtiles 
 bool fuse0_applies(const ts2d_engine* e, int H, int W) {
     // (split mode only.  Measured in the 16-bit mode, B = 64 canonical: 0.30 + 0.94 ms fused against 0.44 + 0.52 ms as two kernels - the
     //  16-bit second block is HBM-bound at a third of the split block's MFMA work, and the recompute is fp32 MFMA work either way)
+    //  Round 6, with the recompute on the fp16 matrix path and the statistics pass at 0.25 ms: 0.25 + 0.79 fused against 0.33 + 0.54 - the 16-bit
+    //  conversion of the recomputed values (round to fp16 as if stored, normalise, LeakyReLU in fp16) is what the fused kernel is bound by)
     if (!e->use_fuse0 || !e->use_res || !e->use_one || e->precision != TS2D_PRECISION_F32_SPLIT_F16X3 || e->ops.size() < 3) return false;
     const Op& o0 = e->ops[0]; const Op& o1 = e->ops[1];
     if (!o0.first_direct || o0.cout != 32 || e->arch.input_channels > 2) return false;

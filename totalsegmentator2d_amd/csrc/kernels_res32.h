@@ -111,6 +111,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
     float xv[FUSE ? NK : 1][FUSE ? 9 : 1];                 // the 27 prefetched input values
     float wr0[FUSE ? 9 : 1], scq[FUSE ? 16 : 1], shq[FUSE ? 16 : 1];
     float bq[(FUSE && sizeof(ST) != 4) ? 16 : 1];
+    // Round 6: the recompute on the fp16 matrix path (as conv3x3_first_split computes the statistics): lane half h2 = input channel, its 8 K entries of
+    // the four v_mfma_f32_32x32x16_f16 are  m0: hi, lo of taps 0-3 | m1: hi, lo of taps 4-7 | m2: hi, lo, hi of tap 8 | m3: hi of taps 0-7  against the
+    // weights  whi whi | whi whi | whi whi wlo | wlo  (x_hi w_hi + x_lo w_hi + x_hi w_lo; w scaled by the power of two S that puts max|w| into [2^11, 2^12)).
+    // 128 instead of 576 matrix-pipe cycles per M tile and ~ 20 VALU to split the lane's nine values.  A wave whose patch holds |x| >= 65 504 (fp16's
+    // range; no pre-scale here) takes the exact fp32 MFMAs with the SAME scaled weights (a power of two: exact), so both paths share scq.
+    typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+    u32x4w wsp[FUSE ? 4 : 1];
+    float inv_s0 = 1.f;
     const bool have3 = w != 3;                             // (wave-uniform)
     __amdgpu_buffer_rsrc_t rs, rsx;
     if constexpr (!FUSE) {
@@ -137,13 +145,36 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
         rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x0) + (size_t)n * a.C0 * a.H * a.W, 0, (int)in_bytes, 0x00020000);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) wr0[tap] = h2 < a.C0 ? a.w0[((size_t)r2 * a.C0 + h2) * 9 + tap] : 0.f;      // A[m = channel r2][k = input channel h2]
+        {
+            float wmax = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wmax = fmaxf(wmax, fabsf(wr0[tap]));
+#pragma unroll
+            for (int d = 1; d < 64; d *= 2) wmax = fmaxf(wmax, __shfl_xor(wmax, d));
+            int e2 = 0;
+            (void)frexpf(wmax, &e2);
+            const bool sane = wmax > 0.f && wmax < 3.0e38f;
+            const float S0 = sane ? ldexpf(1.f, 12 - e2) : 1.f;
+            inv_s0 = sane ? ldexpf(1.f, e2 - 12) : 1.f;
+            unsigned short wh[9], wl[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                wr0[tap] *= S0;                                                       // (exact: a power of two)
+                const _Float16 hh = (_Float16)wr0[tap], ll = (_Float16)(wr0[tap] - (float)hh);
+                wh[tap] = __builtin_bit_cast(unsigned short, hh); wl[tap] = __builtin_bit_cast(unsigned short, ll);
+            }
+            auto pk = [](unsigned short lo_, unsigned short hi_) { return (unsigned)lo_ | ((unsigned)hi_ << 16); };
+            wsp[0] = u32x4w{pk(wh[0], wh[1]), pk(wh[2], wh[3]), pk(wh[0], wh[1]), pk(wh[2], wh[3])};
+            wsp[1] = u32x4w{pk(wh[4], wh[5]), pk(wh[6], wh[7]), pk(wh[4], wh[5]), pk(wh[6], wh[7])};
+            wsp[2] = u32x4w{pk(wh[8], wh[8]), pk(wl[8], 0), 0u, 0u};
+            wsp[3] = u32x4w{pk(wl[0], wl[1]), pk(wl[2], wl[3]), pk(wl[4], wl[5]), pk(wl[6], wl[7])};
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {                     // rows of the 32x32 product held by this lane: channel (i & 3) + 8 (i >> 2) + 4 h2
             const int c = (i & 3) + 8 * (i >> 2) + 4 * h2;
             const float s_ = a.sc[(size_t)n * 32 + c], t_ = a.sh[(size_t)n * 32 + c], b_ = a.b0[c];
-            scq[i] = s_;
-            if constexpr (sizeof(ST) == 4) shq[i] = __builtin_fmaf(b_, s_, t_);      // (acc + b) s + t = acc s + (b s + t)
-            else { shq[i] = t_; bq[i] = b_; }                                       // 16-bit mode: the raw value is rounded to fp16 first, as if stored
+            if constexpr (sizeof(ST) == 4) { scq[i] = s_ * inv_s0; shq[i] = __builtin_fmaf(b_, s_, t_); }      // (acc / S + b) s + t = acc (s / S) + (b s + t)
+            else { scq[i] = s_; shq[i] = t_; bq[i] = b_; }                          // 16-bit mode: the raw value is rounded to fp16 first, as if stored
         }
     }
     auto prefetch = [&](int ptx, int pty) {
@@ -245,8 +276,24 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
         for (int k = 0; k < NK; ++k) {
             if (k < NK - 1 || have3) {
                 f32x16 acc0 = kZero16;
+                float amax = 0.f;
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wr0[tap], xv[k][tap], acc0, 0, 0, 0);
+                for (int tap = 0; tap < 9; tap += 3) amax = fmaxf(amax, fmaxf(fabsf(xv[k][tap]), fmaxf(fabsf(xv[k][tap + 1]), fabsf(xv[k][tap + 2]))));
+                if (__builtin_amdgcn_ballot_w64(!(amax < 65504.f)) == 0) {          // (wave-uniform) every value splits into two finite fp16 parts
+                    uint4 xh, xl;
+                    split_hi_lo_8(f32x4{xv[k][0], xv[k][1], xv[k][2], xv[k][3]}, f32x4{xv[k][4], xv[k][5], xv[k][6], xv[k][7]}, xh, xl);
+                    const _Float16 h8 = (_Float16)xv[k][8], l8 = (_Float16)(xv[k][8] - (float)h8);
+                    const unsigned uh8 = __builtin_bit_cast(unsigned short, h8), ul8 = __builtin_bit_cast(unsigned short, l8);
+                    const u32x4w xb0 = u32x4w{xh.x, xh.y, xl.x, xl.y}, xb1 = u32x4w{xh.z, xh.w, xl.z, xl.w};
+                    const u32x4w xb2 = u32x4w{uh8 | (ul8 << 16), uh8, 0u, 0u}, xb3 = u32x4w{xh.x, xh.y, xh.z, xh.w};
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wsp[0]), __builtin_bit_cast(half8, xb0), acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wsp[1]), __builtin_bit_cast(half8, xb1), acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wsp[2]), __builtin_bit_cast(half8, xb2), acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wsp[3]), __builtin_bit_cast(half8, xb3), acc0, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wr0[tap], xv[k][tap], acc0, 0, 0, 0);
+                }
                 const bool zero = (hit >> (4 * k)) & 0xFu;                        // this lane's pixel lies outside the image
                 const int p = 32 * (w + 4 * k) + r2;
                 unsigned char* d = sP + p * 16 + 8 * h2;                          // plane g = quad index: + g * kResPS; lo part: + 4 * kResPS
@@ -276,7 +323,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv3x3_res32(const Res32Args a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int i = 4 * q + e;
-                            const float raw = (float)(_Float16)(acc0[i] + bq[i]);                     // as stored by conv3x3_first in this mode
+                            const float raw = (float)(_Float16)__builtin_fmaf(acc0[i], inv_s0, bq[i]);    // as stored by conv3x3_first in this mode
                             const _Float16 y = (_Float16)__builtin_fmaf(raw, scq[i], shq[i]);         // norm_lrelu_8: fp32 FMA, one rounding,
                             const _Float16 ng = y * slope_h;                                          // LeakyReLU in fp16
                             o[e] = zero ? (_Float16)0.f : (y > ng ? y : ng);
