@@ -33,7 +33,12 @@ def short(k):
     k = re.sub(r'\(.*$', '', k)
     m = re.match(r'([A-Za-z0-9_]+)(?:<(\d+))?', k)
     base, first = m.group(1), m.group(2)
-    if base in ('conv3x3_f16x3_p', 'conv3x3_f16x3_one', 'conv3x3_h32', 'conv3x3_upc', 'conv3x3s2_v2') and first:
+    targs = [t.strip() for t in k.split('<', 1)[-1].rsplit('>', 1)[0].split(',')] if '<' in k else []
+    if base == 'conv3x3s2_v2' and first:
+        return f'{base}<{first},k32>' if len(targs) >= 6 and targs[5] == 'true' else f'{base}<{first}>'      # (K32: 32-channel chunks, 16-bit mode)
+    if base == 'conv3x3_first_split':
+        return 'conv3x3_first_stats' if targs and targs[-1] == 'false' else 'conv3x3_first_split'          # STORE = false: the statistics-only pass
+    if base in ('conv3x3_f16x3_p', 'conv3x3_f16x3_one', 'conv3x3_h32', 'conv3x3_upc') and first:
         return f'{base}<{first}>'
     if base == 'conv3x3_res32' and 'true' in k.split('<', 1)[-1].split('>')[0].split(',')[-1]:
         return 'conv3x3_res32f'                                   # the FUSE instantiation (first block recomputed inside)
