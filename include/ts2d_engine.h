@@ -131,7 +131,9 @@ int ts2d_engine_forward(ts2d_engine* e, const float* input, int B, int H, int W,
  * with ts2d_last_error() naming the first layer (program order) whose output holds a non-finite value.  The split and f16 modes
  * multiply fp16 operands: an activation of magnitude >= 65504 at a conv input (impossible after InstanceNorm for |gamma| < 127,
  * possible for an un-normalised transposed-conv output with adversarial weights) overflows to inf - this check turns that into an
- * error instead of a silent inf; TS2D_PRECISION_F32_EXACT has no such limit.  Host-buffer forwards and ts2d_engine_predict_tiled
+ * error instead of a silent inf; TS2D_PRECISION_F32_EXACT has no such limit.  (The network INPUT is not under that limit: the first block
+ * checks every tile's input inside its kernel and computes a tile that holds |x| >= 262 016, an inf or a NaN with the exact fp32
+ * MFMAs - same result, slower.)  Host-buffer forwards and ts2d_engine_predict_tiled
  * run it themselves; after an asynchronous device-pointer forward the caller may.  (Reference convention: a failing prediction
  * raises, ts2d/core/inference/prediction_worker.py:211-212; upstream nnU-Net only checks the aggregated array for inf.) */
 int ts2d_engine_check(ts2d_engine* e);
