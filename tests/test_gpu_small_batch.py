@@ -115,3 +115,36 @@ def test_small_batch_inside_a_workspace_planned_for_a_large_one():
         assert np.abs(one[0] - big[3]).max() <= 3e-5
         again, _ = e.forward(x, logits=True)
         assert np.array_equal(again, big)
+
+
+@pytest.mark.parametrize('mode', ['split', 'f16'])
+def test_small_batches_in_one_shared_workspace(mode):
+    """The sub-models of a set share ONE caller-provided workspace (SubModelSet; BASELINE config 3).  Reserved for a batch of 12 (whose plan
+    composes every decoder entry), then driven with 2 slices - split-K partials and the scratch for an un-composed upsampled tensor live
+    inside the shared memory: bit-identical to engines with memory of their own, at both batch sizes, in either order."""
+    import torch
+    from totalsegmentator2d_amd.submodels import SubModelSet
+    models = []
+    for mid, K, seed in (('a_small', 3, 31), ('b_wide', 26, 32)):
+        arch = cases.unet(5, (32, 64, 128, 256, 512), K)
+        models.append((mid, arch, blob_for(arch, seed)[1]))
+    xb = torch.from_numpy(cases.make_input(models[0][1], 12, 128, 160, 5)).cuda()
+    xs = xb[4:6].contiguous()
+    want = {}
+    for mid, arch, blob in models:
+        with Engine(arch, blob) as e:
+            e.set_precision(mode)
+            e.set_profiling(True)
+            for tag, x in (('small', xs), ('big', xb)):
+                _, m = e.forward(x, logits=False, mask=True)
+                torch.cuda.synchronize()
+                want[mid, tag] = m.cpu().numpy().copy()
+                if tag == 'small':
+                    assert any(n.endswith('.up') and int(n[3]) < 3 for n in e.op_kernels()), sorted(e.op_kernels())      # the path under test
+    with SubModelSet(models, precision=mode) as ms:
+        ms.reserve(12, 128, 160)
+        for tag, x in (('small', xs), ('big', xb), ('small', xs)):
+            got = ms.forward_masks(x)
+            torch.cuda.synchronize()
+            for (mid, _, _), g in zip(models, got):
+                assert np.array_equal(g.cpu().numpy(), want[mid, tag]), (mid, tag)
