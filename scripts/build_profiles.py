@@ -4,7 +4,7 @@
 
 Writes profiles/<tag>_bench.json, <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_pmc_traffic.json (+ the
 pmc_traffic.json bench.py reads; FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections), <tag>_sq_counters.txt and
-<tag>_phase_stamps.txt (in-kernel stamps, TS2D_DBG=256)."""
+<tag>_phase_stamps.txt (in-kernel stamps, TS2D_DBG=256), <tag>_resources.txt (VGPR / AGPR / SGPR / spills / scratch per kernel instantiation)."""
 import collections, csv, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -55,6 +55,8 @@ def main():
     for name in ('pmc_traffic.json', f'{tag}_pmc_traffic.json'):
         open(os.path.join(P, name), 'w').write(pj)
     open(os.path.join(P, f'{tag}_sq_counters.txt'), 'w').write(sq_table(os.path.join(src, 'pmc_sq', 'runc_counter_collection.csv'), tag))
+    # register / scratch / LDS table of every kernel instantiation (hipcc cross-compiles here: amdhsa metadata)
+    subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'kernel_resources.py'), os.path.join(P, f'{tag}_resources.txt')], check=True, capture_output=True)
     st = os.path.join(src, 'phase_stamps.txt')
     if os.path.exists(st):
         lines = [l for l in open(st) if l.startswith('[phases]') or l.startswith('[split')]
