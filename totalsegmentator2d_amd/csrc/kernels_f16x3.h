@@ -84,6 +84,15 @@ __device__ __forceinline__ void split_hi_lo_4(const f32x4& v, uint2& hi, uint2& 
     hi = uint2{h0, h1}; lo = uint2{l0, l1};
 }
 
+// buffer store of one activation in the storage type (a per-lane byte offset + a wave-uniform one)
+template <typename ST> __device__ __forceinline__ void buffer_store_act(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ void buffer_store_act<float>(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void buffer_store_act<_Float16>(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), rs, voff, soff, 0);
+}
+
 // Shared epilogue: undo the weight pre-scale, add bias, store the raw NHWC output, per-tile InstanceNorm partials.
 // C/D map of the 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).
 
@@ -94,6 +103,34 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const int NIMG = a.NIMG;
     const float oscale = *a.oscale;
+    if (a.part == nullptr && NIMG > 1 && a.TH == a.Ht && a.TW == a.Wt && NIMG * a.TH * a.TW == 256) {
+        // tile = NIMG WHOLE images (the <= 8 x 8 levels) and no statistics from here (split-K slice, or stats_direct behind the op): GEMM row m is pixel
+        // nimg0 * HW + m of the flattened [B * H * W][Cout] output - one lane offset per block, a scalar offset per row, images beyond the batch dropped by
+        // the buffer's range check (round 6; the loop below spends ~ 30 VALU per row on divisions, bounds tests and 64-bit addresses)
+        const size_t slice = a.ksplit > 1 ? (size_t)blockIdx.y * a.kslice_stride : 0;
+        const size_t all_b = (size_t)a.B * a.Ht * a.Wt * a.Cout * (a.ksplit > 1 ? sizeof(float) : sizeof(ST));
+        const auto rp = __builtin_amdgcn_make_buffer_rsrc(a.ksplit > 1 ? reinterpret_cast<unsigned char*>(reinterpret_cast<float*>(a.dst) + slice)
+                                                                       : reinterpret_cast<unsigned char*>(a.dst), 0, (int)all_b, 0x00020000);
+        if (all_b < ((size_t)1 << 31)) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = n0col + nt * 32 + r;
+                const float bv = a.ksplit > 1 ? 0.f : a.bias[co];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const unsigned px0 = (unsigned)(nimg0 * a.Ht * a.Wt + 64 * w + 32 * mt + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int rowoff = (i & 3) + 8 * (i >> 2);
+                        const float v = __builtin_fmaf(acc_t[mt][nt][i], oscale, bv);
+                        if (a.ksplit > 1) buffer_store_act<float>(v, rp, (px0 * a.Cout + co) * 4u, (unsigned)(rowoff * a.Cout * 4));
+                        else buffer_store_act<ST>(v, rp, (px0 * a.Cout + co) * (unsigned)sizeof(ST), (unsigned)(rowoff * a.Cout * (int)sizeof(ST)));
+                    }
+                }
+            }
+            return;
+        }
+    }
     float st_s[NT], st_q[NT], st_k[NT], st_n[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { st_s[nt] = 0.f; st_q[nt] = 0.f; st_n[nt] = 0.f; }
@@ -143,24 +180,40 @@ __device__ __forceinline__ void split_epilogue(const ConvArgs& a, f32x16 (&acc_t
 // a tile row since TW >= 16): buffer stores with one per-lane base offset per 32x32 block and a scalar offset per row - no
 // per-element address arithmetic, bounds tests or exec-mask regions (the generic epilogue spends ~30 VALU + 14 SALU per row).
 // Same values, same statistics order as split_epilogue.
-template <typename ST> __device__ __forceinline__ void buffer_store_act(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff);
-template <> __device__ __forceinline__ void buffer_store_act<float>(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
-}
-template <> __device__ __forceinline__ void buffer_store_act<_Float16>(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), rs, voff, soff, 0);
-}
 
 template <int BN, typename ST = float>
 __device__ __forceinline__ void split_epilogue_one(const ConvArgs& a, f32x16 (&acc_t)[2][BN / 32], unsigned char* smem8,
                                                    int n0col, int nimg0, int ty0, int tx0, int tpi, int tin) {
     constexpr int NT = BN / 32;
     const int TH = a.TH, TW = a.TW;
-    const bool full = a.ksplit == 1 && a.lgTW >= 4 && a.lgTH + a.lgTW == 8 && ty0 + TH <= a.Ht && tx0 + TW <= a.Wt && nimg0 < a.B;     // wave-uniform
+    const bool whole = a.lgTW >= 4 && a.lgTH + a.lgTW == 8 && ty0 + TH <= a.Ht && tx0 + TW <= a.Wt && nimg0 < a.B;     // wave-uniform
+    const bool full = a.ksplit == 1 && whole;
     // (power-of-two tiles of 256 pixels only: lgTW = -1 for the tile shapes of ragged levels, which take the general epilogue)
-    if (!full) { split_epilogue<BN, ST>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const float oscale = *a.oscale;
+    if (a.ksplit > 1 && whole) {
+        // split-K slice (round 6: the small-batch dispatch runs every <= 32 x 32 level this way): un-biased fp32 partials, no statistics - the same
+        // one-offset-per-block addressing as below instead of the general epilogue's ~ 30 VALU per row; values as split_epilogue writes them
+        const size_t img_f = (size_t)a.Ht * a.Wt * a.Cout;
+        const auto rp = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(a.dst) + (size_t)blockIdx.y * a.kslice_stride + (size_t)nimg0 * img_f, 0,
+                                                          (int)(img_f * sizeof(float)), 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m0 = 64 * w + 32 * mt + 4 * h;
+                const int oy = ty0 + (m0 >> a.lgTW), ox = tx0 + (m0 & (TW - 1));
+                const unsigned voff = (unsigned)(((oy * a.Wt + ox) * a.Cout + n0col + nt * 32 + r) * 4);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rowoff = (i & 3) + 8 * (i >> 2);
+                    const unsigned soff = (unsigned)((((rowoff & (TW - 1)) + (rowoff >> a.lgTW) * a.Wt) * a.Cout) * 4);       // scalar
+                    buffer_store_act<float>(__builtin_fmaf(acc_t[mt][nt][i], oscale, 0.f), rp, voff, soff);
+                }
+            }
+        return;
+    }
+    if (!full) { split_epilogue<BN, ST>(a, acc_t, smem8, n0col, nimg0, ty0, tx0, tpi, tin); return; }
     const size_t img_el = (size_t)a.Ht * a.Wt * a.Cout;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<ST*>(a.dst) + (size_t)nimg0 * img_el, 0, (int)(img_el * sizeof(ST)), 0x00020000);
     float st_s[NT], st_q[NT], st_k[NT];
