@@ -60,6 +60,26 @@ def test_concurrent_sub_models_equal_the_serial_order():
             assert max(t['preprocessed'] for t in ta) < min(t['predicted'] for t in ta) or len(ids) == 1
 
 
+def test_device_thresholded_segmentation_equals_the_logits_path():
+    """Round 6: where the export step needs no logits (multilabel, one fold, no resampling) ``HIPModel`` takes the segmentation thresholded on
+    the device (K uint8 planes to the host instead of K float16 ones; kernels_sw.h) - the reference's seam, ``predict_logits_from_preprocessed_data``
+    + ``export_prediction_from_logits`` (ts2d/core/inference/prediction_worker.py:209-221), must give the same bytes and metadata."""
+    ids = ('ts2d-v2-ep4000b2_cardiac', 'ts2d-v2-ep4000b2_ribs')
+    models = {m: synthetic_model(m, 3 + 2 * i, 51 + i, patch=(64, 64), mirror=True)[0] for i, m in enumerate(ids)}
+    with TS2D(models=models) as ts:
+        for asset in ('sample_s0521.nrrd', 'sample_s0616.nrrd'):
+            for m in ts.models.values():
+                m.device_threshold = True
+            a = ts.predict(os.path.join(A, asset))
+            for m in ts.models.values():
+                m.device_threshold = False
+            b = ts.predict(os.path.join(A, asset))
+            assert np.array_equal(a.get_segmentation().array, b.get_segmentation().array) and a.get_segmentation().meta == b.get_segmentation().meta
+            for m in ids:
+                assert np.array_equal(a.get_segmentation(m).array, b.get_segmentation(m).array)
+            assert a.get_segmentation().array.any()
+
+
 def test_gpu_projection_equals_oracle_projection():
     """ts2d_project_coronal (strided view, no reorientation copy) against oracle/input_oracle.py (DICOMOrient 'RAI' + ITK max /
     mean projection + Float32 cast; the mean is real-valued, pinned by the reference's assets in tests/test_oracle.py): bit for

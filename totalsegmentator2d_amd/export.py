@@ -18,6 +18,11 @@ from .image import set_annotation_meta
 SIGMOID_HALF_THRESHOLD = np.float32(1.5 * 2.0 ** -24)     # sigmoid(float32 x) > 0.5  <=>  x > 1.5 * 2^-24 (tests/test_oracle.py)
 
 
+def needs_logits(properties: dict, shape_khw) -> bool:
+    """Does the export resample the prediction back to another shape (then it needs logits, not a thresholded segmentation)?"""
+    return tuple(properties.get('shape_after_cropping_and_before_resampling', tuple(shape_khw))) != tuple(shape_khw)
+
+
 def convert_predicted_logits_to_segmentation_with_correct_shape(logits, properties: dict, multilabel: bool = True,
                                                                 transpose_backward=(0, 1, 2)) -> np.ndarray:
     """[K, Z, H, W] logits (any float dtype) -> uint8 segmentation in the ORIGINAL (pre-crop) array shape:
@@ -33,7 +38,9 @@ def convert_predicted_logits_to_segmentation_with_correct_shape(logits, properti
     bbox = properties['bbox_used_for_cropping']
     sl = tuple(slice(b[0], b[1]) for b in bbox)
     if multilabel:
-        if lg.dtype == np.float16:
+        if lg.dtype == np.uint8:
+            seg = lg          # already thresholded on the device (HIPnnUNetPredictor.predict_segmentation_from_preprocessed_data): same predicate
+        elif lg.dtype == np.float16:
             # float32(x) > 1.5 * 2^-24 on the fp16 bit pattern: positive, at least the SECOND subnormal (the first, 2^-24, is
             # below the threshold), +inf included, NaN excluded - the same predicate without a float32 copy of the array
             v = np.ascontiguousarray(lg).view(np.uint16)

@@ -37,6 +37,7 @@ class HIPModel:
         self.labels: Optional[Dict[int, str]] = None
         self.colors = self._param.get('nnu.result.colors')
         self._dataset_json: Optional[dict] = None
+        self.device_threshold = True     # thresholded segmentation straight from the device where the export needs no logits (_apply_one)
         self._discover()
 
     # ------------------------------------------------------------------ configuration (reference wrapper.py:113-162)
@@ -160,8 +161,18 @@ class HIPModel:
         except Exception as ex:
             raise RuntimeError(f"Preprocessing failed for {name}: {ex}") from ex
         try:
-            logits = p.predict_logits_from_preprocessed_data(data)
-            logits = logits.cpu().numpy() if hasattr(logits, 'cpu') else logits
+            logits = None
+            # product fast path: a multilabel 2-D case whose export does not resample gets its segmentation thresholded on the device
+            # (K uint8 planes to the host instead of K float16 ones; the predicate is the export step's, bit for bit) - the reference's seam
+            # (predict_logits_from_preprocessed_data + export_prediction_from_logits) stays as it is and serves every other case
+            if self.device_threshold and bool(p.dataset_json.get('multilabel', p.dataset_json.get('multiclass', False))) \
+                    and hasattr(p, 'predict_segmentation_from_preprocessed_data'):
+                from .export import needs_logits
+                if not needs_logits(props, np.asarray(data).shape[1:]):
+                    logits = p.predict_segmentation_from_preprocessed_data(data)
+            if logits is None:
+                logits = p.predict_logits_from_preprocessed_data(data)
+                logits = logits.cpu().numpy() if hasattr(logits, 'cpu') else logits
             ts['predicted'] = time.time()
         except Exception as ex:
             raise RuntimeError(f"Prediction failed for {name}: {ex}") from ex

@@ -182,6 +182,32 @@ class HIPnnUNetPredictor:
                                'value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits to fp32')
         return logits[(slice(None),) + revert[1:]]
 
+    def predict_segmentation_from_preprocessed_data(self, data):
+        """Fast path of the product surface (not part of the reference's duck-typed seam): the multilabel segmentation
+        ``sigmoid(float(half logits)) > 0.5`` thresholded ON THE DEVICE by the aggregation kernel (kernels_sw.h: the same predicate as
+        export.py's bit-pattern test, verified on all 65 536 half values), so that K uint8 planes travel to the host instead of K float16
+        ones and the host never thresholds.  One fold, one z-slice (the 2-D models of ts2d); returns uint8 [K, 1, H, W] in the
+        preprocessed geometry, or None when the case needs the logits (fold ensembles average logits first; 3-D stacks)."""
+        if hasattr(data, 'detach'):
+            data = data.detach().cpu().numpy()
+        data = np.asarray(data, dtype=np.float32)
+        if len(self.list_of_parameters) != 1 or len(self.engines) != 1 or data.ndim != 4 or data.shape[1] != 1:
+            return None
+        patch = tuple(self.configuration_manager.patch_size)
+        padded, revert = sw.pad_nd_image(data, patch)
+        C, Z, H, W = padded.shape
+        slicers = sw.tile_slicers((H, W), patch, self.tile_step_size, Z)
+        if self.use_mirroring and self.allowed_mirroring_axes and max(self.allowed_mirroring_axes) > 1:
+            raise AssertionError('mirror_axes does not match the dimension of the input!')
+        g = sw.compute_gaussian(patch) if self.use_gaussian else None
+        axes = self.allowed_mirroring_axes if self.use_mirroring else None
+        tiles = [(sx, sy) for (dd, sx, sy) in slicers if dd == 0]
+        _, seg = self.engines[0].predict_tiled(padded[:, 0], patch, tiles, axes, g, want_logits=False, want_seg=True)
+        if self.engines[0].last_tiled_inf:
+            raise RuntimeError('Encountered inf in predicted array. Aborting... If this problem persists, reduce '
+                               'value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits to fp32')
+        return seg[:, None][(slice(None),) + revert[1:]]
+
     def predict_logits_from_preprocessed_data(self, data):
         """Fold ensemble (upstream: sum over ``list_of_parameters`` then ``/= n``).  Accepts numpy or torch [C,1,H,W];
         returns a torch CPU tensor (float16) when torch is importable so that the caller's ``.cpu()`` works."""
