@@ -135,6 +135,16 @@ class HIPModel:
                 raise RuntimeError(f"Prediction failed for: {name}: {ex}") from ex
         return next(iter(results.values())) if single else results
 
+    @staticmethod
+    def _preprocess_key(p, props) -> str:
+        """Everything DefaultPreprocessor.run_case_npy reads besides the image itself: two sub-models with the same key preprocess identically."""
+        cm, pm = p.configuration_manager, p.plans_manager
+        dz = props.get('device_zscore')
+        return repr((list(getattr(pm, 'transpose_forward', [0, 1, 2])), list(cm.spacing), list(getattr(cm, 'normalization_schemes', None) or []),
+                     list(getattr(cm, 'use_mask_for_norm', None) or []), sorted((p.dataset_json.get('channel_names') or {}).items()),
+                     (getattr(pm, 'plans', None) or {}).get('foreground_intensity_properties_per_channel', {}),
+                     None if dz is None else tuple(dz.get('order', ()))))
+
     def _apply_one(self, name, img, result_dir, override):
         """The reference worker's four stages (``prediction_worker.py:177-242``), each failing under its own name -
         ``"<Stage> failed for <name>: <cause>"`` - so that a HIP error (``ts2d_last_error``) tells which stage raised it."""
@@ -156,7 +166,18 @@ class HIPModel:
             if getattr(ref, 'device_zscore', None) is not None:
                 props['device_zscore'] = ref.device_zscore      # z-score done on the device behind the projection (image.py)
             pre = p.configuration_manager.preprocessor_class(verbose=p.verbose)
-            data, _, props = pre.run_case_npy(data, None, props, p.plans_manager, p.configuration_manager, p.dataset_json)
+            shared = getattr(ref, 'preprocess_cache', None)      # set by TS2D.predict: the sub-models of one case mostly share channels and plan
+            if shared is None:
+                data, _, props = pre.run_case_npy(data, None, props, p.plans_manager, p.configuration_manager, p.dataset_json)
+            else:
+                key = self._preprocess_key(p, props)
+                with shared['lock']:                             # (the first sub-model computes, its siblings wait for the result instead of repeating it)
+                    hit = shared['items'].get(key)
+                    if hit is None:
+                        d2, _, p2 = pre.run_case_npy(data, None, props, p.plans_manager, p.configuration_manager, p.dataset_json)
+                        d2.setflags(write=False)
+                        hit = shared['items'][key] = (d2, p2)
+                data, props = hit[0], dict(hit[1])
             ts['preprocessed'] = time.time()
         except Exception as ex:
             raise RuntimeError(f"Preprocessing failed for {name}: {ex}") from ex

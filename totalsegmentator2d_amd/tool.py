@@ -160,6 +160,9 @@ class TS2D:
         if dz is not None and not native_2d and all(n.lower() in ('max', 'mip', 'mean', 'avg') for _, n in channels):
             # channel order of THIS model over the (max, mean) planes the device normalised
             input2d.device_zscore = dict(dz, order=tuple(0 if n.lower() in ('max', 'mip') else 1 for _, n in channels))
+        # one preprocessing per distinct (channels, plan) of the case, shared by the sub-models (they run on threads: model.py takes the lock)
+        import threading
+        input2d.preprocess_cache = cache.setdefault('preprocessed', {'lock': threading.Lock(), 'items': {}})
         return input, input2d, native_2d
 
     def _apply_model(self, mid: str, prepared, collapse: bool) -> dict:
